@@ -1,0 +1,41 @@
+"""Shared helpers for the parity tests: fixture loading and weight regeneration."""
+import os
+
+import numpy as np
+
+from trebi_amd import spec, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CONFIG_NAMES = ('pendulum', 'halfcheetah', 'hopper', 'walker148')
+
+
+def load_fixture(name):
+    return dict(np.load(os.path.join(GOLDEN, f'{name}.npz')))
+
+
+def fixture_weights(fx):
+    """Rebuild the three synthetic state_dicts a fixture was generated with."""
+    H, D, dim = int(fx['H']), int(fx['obs']) + int(fx['act']), int(fx['dim'])
+    um = tuple(int(m) for m in fx['unet_mults'])
+    vm = tuple(int(m) for m in fx['value_mults'])
+    s_u, s_r, s_c = (int(s) for s in fx['seeds'][:3])
+    sd_u = synth.synth_state_dict(spec.unet_param_shapes(H, D, dim, um), s_u)
+    sd_r = synth.synth_state_dict(spec.value_param_shapes(H, D, dim, vm), s_r)
+    sd_c = synth.synth_state_dict(spec.value_param_shapes(H, D, dim, vm), s_c)
+    return sd_u, sd_r, sd_c, um, vm
+
+
+def fixture_kwargs(fx):
+    kw = {}
+    for k in fx:
+        if k.startswith('kw_'):
+            v = fx[k]
+            kw[k[3:]] = (bool(v) if v.dtype == bool else int(v) if np.issubdtype(v.dtype, np.integer) else float(v))
+    return kw
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b| -- the relative error the parity bars are stated in."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
