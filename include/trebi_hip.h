@@ -1,0 +1,194 @@
+/*
+ * trebi_hip.h -- C ABI of the MI355X (gfx950) implementation of TREBI's
+ * cost-guided diffusion-planning hot path.
+ *
+ * The reference (qianlin04/Safe-offline-RL-with-diffusion-model) is pure
+ * Python/PyTorch and has no FFI of its own; each entry point below names the
+ * reference interface (file:line under /root/reference) it replaces.  Plain C
+ * types only: device pointers are `float*` / `int64_t*` on the context's GPU,
+ * streams are passed as `void*` (a hipStream_t).  Every call returns 0 on
+ * success or a negative trebi_status; trebi_last_error() gives the message of the
+ * last failure on the calling thread.  No call synchronises the device and,
+ * except the *_create / *_destroy pairs, no call allocates: workspaces are
+ * caller-owned (size from the *_workspace_bytes queries).
+ *
+ * Tensor conventions (all float32, contiguous unless a row stride is given):
+ *   x, grad, trajectories : [B, horizon, ldx]   (ldx >= transition_dim; the nets read the
+ *                                                first transition_dim columns, guides.py:13)
+ *   t                     : [B] int64 diffusion timesteps in [0, max_timesteps)
+ *   cond                  : [B, observation_dim] per conditioned horizon index
+ */
+#ifndef TREBI_HIP_H
+#define TREBI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  TREBI_OK = 0,
+  TREBI_BAD_ARG = -1,            /* null pointer, negative size, unknown enum value         */
+  TREBI_BAD_SHAPE = -2,          /* tensor table does not match the architecture descriptor */
+  TREBI_UNSUPPORTED_CONFIG = -3, /* valid in the reference but outside what the kernels tile */
+  TREBI_WORKSPACE_TOO_SMALL = -4,
+  TREBI_HIP_ERROR = -5
+} trebi_status;
+
+typedef struct trebi_ctx trebi_ctx;         /* one per device                          */
+typedef struct trebi_net trebi_net;         /* packed TemporalUnet or ValueFunction    */
+typedef struct trebi_sampler trebi_sampler; /* a captured p_sample_loop for a fixed B  */
+
+const char* trebi_last_error(void);
+int trebi_version(void);
+
+/* ---- context -------------------------------------------------------------------- */
+int trebi_ctx_create(int device, trebi_ctx** out);
+void trebi_ctx_destroy(trebi_ctx* ctx);
+
+/* ---- networks --------------------------------------------------------------------
+ * kind 0: models.TemporalUnet(horizon, transition_dim, cond_dim, dim, dim_mults, attention=False)
+ *         /root/reference/diffuser/models/temporal.py:49-118
+ * kind 1: models.ValueFunction(horizon, transition_dim, cond_dim, dim, dim_mults, out_dim=1)
+ *         /root/reference/diffuser/models/temporal.py:153-211
+ * Weights are handed over as the reference's state_dict(): `names[i]` is the key
+ * (e.g. "downs.0.0.blocks.0.block.0.weight"), `tensors[i]` a HOST pointer to
+ * `numels[i]` contiguous float32 in the reference's own layout.  The library packs
+ * them into its kernel layout on the device and precomputes, for every integer
+ * timestep t < max_timesteps, the time-embedding biases the blocks add
+ * (temporal.py:28-32,44,70-75; t is batch-uniform on this path, diffusion.py:199).
+ */
+typedef struct {
+  int kind;           /* 0 = TemporalUnet, 1 = ValueFunction */
+  int horizon;
+  int transition_dim;
+  int dim;
+  int n_mults;
+  int dim_mults[8];
+  int max_timesteps;  /* table size for t; GaussianDiffusion.n_timesteps or larger */
+} trebi_net_desc;
+
+int trebi_net_create(trebi_ctx* ctx, const trebi_net_desc* desc, const char* const* names,
+                     const float* const* tensors, const int64_t* numels, int n_tensors,
+                     trebi_net** out);
+void trebi_net_destroy(trebi_net* net);
+
+/* Number of reference state_dict entries the descriptor implies, and the i-th name/numel
+ * (lets the caller check a checkpoint before handing it over; serialization.py:36-60). */
+int trebi_net_param_count(const trebi_net_desc* desc);
+int trebi_net_param_info(const trebi_net_desc* desc, int i, char* name_out, size_t name_cap,
+                         int64_t* numel_out);
+
+/* Algorithmic FLOPs per candidate of one forward (backward=0) or one backward-to-input
+ * (backward=1) pass: 2 flop per multiply-add of the convolutions and linears, structurally
+ * zero padding taps excluded.  No counterpart in the reference. */
+double trebi_net_flops(const trebi_net* net, int backward);
+
+/* TemporalUnet.forward(x, cond, time) -> [B, horizon, transition_dim]
+ * /root/reference/diffuser/models/temporal.py:120-151 (cond is unused there). */
+size_t trebi_unet_workspace_bytes(const trebi_net* net, int B);
+int trebi_unet_forward(trebi_net* net, const float* x, int ldx, const int64_t* t, float* out,
+                       int ldo, int B, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ValueFunction.forward(x, cond, time)[:, 0] -> y[B]
+ * /root/reference/diffuser/models/temporal.py:213-239, guides.py:12-14.
+ * With grad != NULL also ValueGuide.gradients (guides.py:16-21): grad[B,horizon,ldg] =
+ * d(sum y)/dx (columns >= transition_dim are written as 0), by an explicit
+ * backward-to-input chain -- no autograd tape, no weight gradients. */
+size_t trebi_value_workspace_bytes(const trebi_net* net, int B);
+int trebi_value_gradients(trebi_net* net, const float* x, int ldx, const int64_t* t, float* y,
+                          float* grad /* nullable */, int ldg, int B, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ---- elementwise steps of the sample functions ------------------------------------
+ * One guide-ascent iteration, functions.py:95-119 (constrained) / :21-29 (reward only):
+ *   guide_type 0: g = r_grad - cost_grad * cgw*exp(clamp((c-thr)/thr,0,1)) * [c > thr]
+ *   guide_type 1: g = r_grad - cost_grad * cgw*[c > thr]
+ *   cost_grad == NULL: g = r_grad
+ *   g *= exp(plv[t]) if scale_grad_by_std;  g[:, :, action_dim:] = 0 if state_grad_mask;
+ *   g = 0 where t < t_stopgrad;  x += scale*g;  apply_conditioning (helpers.py:142-145). */
+typedef struct {
+  int horizon, transition_dim, action_dim, observation_dim;
+  int n_timesteps;
+  float scale;
+  int t_stopgrad;
+  int scale_grad_by_std;
+  int state_grad_mask;
+  float cost_grad_weight;
+  int guide_type;
+  int n_cond;          /* number of conditioned horizon indices (keys of the cond dict) */
+  int cond_index[4];
+} trebi_step_desc;
+
+int trebi_guide_update(trebi_ctx* ctx, const trebi_step_desc* d, float* x, const float* r_grad,
+                       const float* cost_grad /* nullable */, const float* cost_y,
+                       const float* cost_threshold, const int64_t* t,
+                       const float* posterior_log_variance /* dev [n_timesteps] */,
+                       const float* const* cond /* n_cond dev ptrs */, int B, void* stream);
+
+/* DDPM reverse step, diffusion.py:166-173 + functions.py:131-137 (predict_epsilon=False):
+ *   x = coef1[t]*x0 + coef2[t]*x + exp(0.5*plv[t]) * noise * [t != 0];  apply_conditioning. */
+int trebi_ddpm_update(trebi_ctx* ctx, const trebi_step_desc* d, float* x, const float* x0,
+                      const float* noise, const int64_t* t, const float* posterior_log_variance,
+                      const float* coef1, const float* coef2, const float* const* cond, int B,
+                      void* stream);
+
+/* Feasibility rule, functions.py:126-129 (global over the n candidates):
+ *   values = -cost_y if no cost_y <= thr else where(cost_y > thr, r_y - 1e8, r_y). */
+int trebi_feasibility_rule(trebi_ctx* ctx, const float* r_y, const float* cost_y,
+                           const float* cost_threshold, int n, float* values_out, void* stream);
+
+/* sort_by_values, diffusion.py:44-49: order_out[k] = index of the k-th largest value
+ * (ties broken by lower index; torch.argsort leaves ties unspecified). */
+int trebi_argsort_desc(trebi_ctx* ctx, const float* values, int n, int64_t* order_out,
+                       void* stream);
+
+/* max_by_values_in_batch, diffusion.py:51-62: best_out[g] = g*per + argmax(values[g*per:(g+1)*per]). */
+int trebi_group_argmax(trebi_ctx* ctx, const float* values, int n_groups, int per,
+                       int64_t* best_out, void* stream);
+
+/* ---- the whole reverse-diffusion loop ---------------------------------------------
+ * GaussianDiffusion.p_sample_loop (diffusion.py:187-206) driving default_sample_fn
+ * (diffusion.py:19-29), n_step_guided_p_sample (functions.py:9-37) or
+ * n_step_guided_and_constrained_p_sample (functions.py:75-137), captured once as a HIP
+ * graph for a fixed candidate count B and replayed with no host synchronisation.  The
+ * final feasibility rule / sort (diffusion.py:208-211) is NOT part of it: candidates may
+ * be sharded over GPUs, so the caller all-gathers (values, costs) and then applies
+ * trebi_feasibility_rule + trebi_argsort_desc to the global arrays. */
+typedef struct {
+  trebi_step_desc step;
+  int kind;            /* 0 default_sample_fn, 1 n_step_guided_p_sample, 2 ..._and_constrained_ */
+  int n_guide_steps;
+  int use_graph;       /* 0: plain stream launches, 1: capture + replay a hipGraph */
+  int skip_dead_evals; /* 1: do not evaluate the guides where their result cannot reach any output
+                          (t < t_stopgrad and t != 0); outputs are bit-identical either way      */
+} trebi_sampler_desc;
+
+int trebi_sampler_create(trebi_ctx* ctx, trebi_net* unet, trebi_net* reward /* nullable */,
+                         trebi_net* cost /* nullable */, const trebi_sampler_desc* desc,
+                         const float* posterior_log_variance, const float* coef1,
+                         const float* coef2 /* HOST [n_timesteps] each */, int B,
+                         trebi_sampler** out);
+void trebi_sampler_destroy(trebi_sampler* s);
+
+/* noise: dev [n_timesteps+1, B, horizon, transition_dim] (noise[0] is x_T, noise[1+k] the k-th step's
+ * draw, diffusion.py:192 / functions.py:134); x_out: dev [B,horizon,transition_dim]; values/costs:
+ * dev [B], the guides' raw outputs at the last step (zeros where the sample function has none);
+ * chain: nullable dev [n_timesteps+1, B, horizon, transition_dim]. */
+int trebi_sampler_run(trebi_sampler* s, const float* noise, const float* const* cond,
+                      const float* cost_threshold /* dev [B], nullable unless kind 2 */,
+                      float* x_out, float* values, float* costs, float* chain, void* stream);
+
+/* Timing hook for bench.py: average duration in microseconds of the implicit-GEMM
+ * kernel launches recorded (with HIP events on the launch stream) during the last
+ * trebi_sampler_run with profiling enabled, and their count / algorithmic FLOPs. */
+int trebi_sampler_set_profiling(trebi_sampler* s, int enabled);
+int trebi_sampler_get_profile(trebi_sampler* s, double* gemm_us_total, int64_t* gemm_launches,
+                              double* gemm_flops_total, double* loop_us_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TREBI_HIP_H */

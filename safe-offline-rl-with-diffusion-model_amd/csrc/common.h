@@ -1,0 +1,115 @@
+// Internal declarations shared by the kernel file and the host-side planner.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace trebi {
+
+constexpr int GN_GROUPS = 8;       // helpers.py:51
+constexpr float GN_EPS = 1e-5f;    // torch.nn.GroupNorm default
+
+// One implicit-GEMM convolution over channels-last activations:
+//   out[b, lo, n] = epi( sum_{tau, ci} x[b, lo*stride + tau - pad, ci] * W[tau][ci][n] + bias[n] )
+//                   + sum_{ci} x2[b, lo, ci] * W2[ci][n] + bias2[n]  + res[b, lo, n]
+// epi = identity, or GroupNorm(8)+Mish (+ per-timestep bias).  With `pro` set the primary
+// source is first turned from dL/d(Mish output) into dL/d(conv output) of the *previous*
+// Conv1dBlock (GroupNorm+Mish backward) while it is staged in LDS.
+struct ConvP {
+  // primary source
+  const float* x;
+  int ldx, Cin, Cin_p;             // Cin_p = Cin rounded up to 16
+  int Lin, Lout, stride, pad;
+  int tap_lo, ntaps;               // structurally non-zero taps: tau = tap_lo .. tap_lo+ntaps-1
+  // optional second source, a 1x1 convolution read at the output positions
+  const float* x2;
+  int ldx2, Cin2, Cin2_p;
+  // weights, packed [(ntaps*Cin_p + Cin2_p)/16][4][Npad][4]
+  const float* w;
+  const float* bias;               // [N] or null
+  const float* bias2;              // [N] or null
+  int N, Npad;
+  // destination
+  float* out;
+  int ldo;
+  int osplit;                      // >0: column n -> position 2*lo + n/osplit, channel n%osplit
+  // epilogue
+  int gn, gch;
+  const float* gamma;
+  const float* beta;
+  float* save_y;                   // [B*Lout, N] conv output before GroupNorm (for the backward)
+  float* save_stats;               // [B, 8, 2] (mean, rstd)
+  const float* tbias;              // [T, N] or null
+  const long long* t;              // [B]
+  int T;
+  const float* res;                // identity residual or null
+  int ldres;
+  // prologue: GroupNorm+Mish backward applied to the primary source
+  int pro, pro_gch;
+  const float* pro_y;              // [B*Lin, Cin]
+  const float* pro_stats;          // [B, 8, 2]
+  const float* pro_gamma;
+  const float* pro_beta;
+  int B;
+};
+
+struct ConvLaunch {
+  ConvP p[2];                      // blockIdx.z selects (reward / cost net run in one launch)
+};
+
+struct Tile {
+  int MI, NI;                      // 16-row / 16-column sub-tiles per wave
+  int NG, KS;                      // waves = NG (column groups) x KS (split of the reduction)
+  int S;                           // whole samples per workgroup
+};
+
+size_t conv_lds_bytes(const ConvP& p, const Tile& tl);
+hipError_t conv_init_device();
+hipError_t launch_conv(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st);
+
+// Value head (temporal.py:237-238) forward + the seed of the backward.
+struct HeadP {
+  const float* v;                  // [B, fc] flattened mid_down2 output
+  const float* w1;                 // [hd, fc] (the time-embedding columns are folded into tb)
+  const float* tb;                 // [T, hd]  W1[:, fc:] @ temb(t) + b1
+  const float* w2;                 // [hd]
+  float b2;
+  const long long* t;
+  int T, fc, hd, B;
+  float* y;                        // [B]
+  float* dv;                       // [B, fc] or null
+};
+struct HeadLaunch { HeadP p[2]; };
+hipError_t launch_head(const HeadLaunch& L, int nz, hipStream_t st);
+
+// Time-embedding tables (computed once per network at load).
+hipError_t launch_time_embed(const float* w1, const float* b1, const float* w2, const float* b2,
+                             int dim, int T, float* temb /*[T,dim]*/, hipStream_t st);
+hipError_t launch_time_linear(const float* w, int ldw, int col0, const float* b, const float* temb,
+                              int dim, int T, int N, int apply_mish, float* out /*[T,N]*/,
+                              hipStream_t st);
+
+struct StepP {
+  int H, D, act, obs, T;
+  float scale;
+  int t_stopgrad, scale_by_std, state_mask;
+  float cgw;
+  int guide_type;
+  int n_cond;
+  int cond_index[4];
+  const float* cond[4];
+};
+hipError_t launch_guide_update(const StepP& s, float* x, const float* rg, const float* cg,
+                               const float* cy, const float* thr, const long long* t,
+                               const float* plv, int B, hipStream_t st);
+hipError_t launch_ddpm_update(const StepP& s, float* x, const float* x0, const float* noise,
+                              const long long* t, const float* plv, const float* c1,
+                              const float* c2, int B, float* chain_out, hipStream_t st);
+hipError_t launch_init_x(const StepP& s, float* x, const float* noise0, int B, float* chain_out,
+                         hipStream_t st);
+hipError_t launch_fill_t(long long* t, int B, int value, hipStream_t st);
+hipError_t launch_feasibility(const float* ry, const float* cy, const float* thr, int n, float* out,
+                              hipStream_t st);
+hipError_t launch_argsort_desc(const float* v, int n, long long* order, hipStream_t st);
+hipError_t launch_group_argmax(const float* v, int ng, int per, long long* best, hipStream_t st);
+
+}  // namespace trebi

@@ -1,0 +1,708 @@
+// Hand-written gfx950 (CDNA4) kernels of the TREBI guided-sampling hot path.
+//
+// conv_gemm_kernel  -- every Conv1d / ConvTranspose1d / input-gradient convolution of
+//                      TemporalUnet and ValueFunction as an implicit GEMM on the f32 matrix
+//                      cores (v_mfma_f32_16x16x4_f32: exact float32, = an fmaf chain), with the
+//                      activations of a few whole candidates staged in LDS, weights streamed
+//                      from L2 straight into registers, an in-workgroup split of the reduction
+//                      across waves, and a fused epilogue: bias, GroupNorm(8)+Mish, time-embedding
+//                      bias, 1x1-residual / identity-residual add; optionally a fused prologue:
+//                      the GroupNorm+Mish backward of the producing block.
+// head_kernel       -- ValueFunction's final MLP forward and the seed of its backward.
+// guide/ddpm update -- the elementwise parts of the sample functions.
+// feasibility / argsort / group argmax -- the selection at the end of p_sample_loop.
+//
+// Layout: activations are channels-last [B, L, ld]; the boundary tensors [B, horizon,
+// transition] already are, so the reference's two einops transposes (temporal.py:125,150)
+// disappear.  Wavefronts are 64 lanes; all block sizes are multiples of 64.
+#include "common.h"
+
+namespace trebi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float softplus_f(float x) {       // torch softplus, threshold 20
+  return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float mish_f(float x) { return x * tanhf(softplus_f(x)); }
+__device__ __forceinline__ float mish_grad_f(float x) {
+  float th = tanhf(softplus_f(x));
+  float sg = 1.f / (1.f + expf(-x));
+  return th + x * sg * (1.f - th * th);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ----------------------------------------------------------------------------------
+// LDS carve (floats), shared between host sizing and the kernel
+// ----------------------------------------------------------------------------------
+struct Carve {
+  int R, ldA, nA, ld2, n2, TM, TN, TNp, red1, body, nstat;
+};
+__host__ __device__ inline Carve make_carve(const ConvP& p, int MI, int NI, int NG, int KS, int S) {
+  Carve c;
+  c.R = (p.Lout - 1) * p.stride + p.ntaps;
+  c.ldA = p.Cin_p + 4;
+  c.nA = S * c.R * c.ldA;
+  c.ld2 = p.x2 ? p.Cin2_p + 4 : 0;
+  c.n2 = p.x2 ? S * p.Lout * c.ld2 : 0;
+  c.TM = 16 * MI;
+  c.TN = 16 * NI * NG;
+  c.TNp = c.TN + 4;
+  c.red1 = KS * c.TM * c.TNp;
+  int red = c.red1 * (p.x2 ? 2 : 1);
+  int stage = c.nA + c.n2;
+  c.body = ((stage > red ? stage : red) + 3) & ~3;
+  int ginst = p.gn ? c.TN / p.gch : 0;
+  c.nstat = 2 * S * (ginst > GN_GROUPS ? ginst : GN_GROUPS);
+  return c;
+}
+
+size_t conv_lds_bytes(const ConvP& p, const Tile& tl) {
+  Carve c = make_carve(p, tl.MI, tl.NI, tl.NG, tl.KS, tl.S);
+  return (size_t)(c.body + c.nstat) * sizeof(float);
+}
+
+template <int MI, int NI>
+__global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int NG, int KS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ConvP& p = L.p[blockIdx.z];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = nthr >> 6;
+  const Carve cv = make_carve(p, MI, NI, NG, KS, S);
+  const int R = cv.R, ldA = cv.ldA, ld2 = cv.ld2, TM = cv.TM, TN = cv.TN, TNp = cv.TNp;
+  float* slab = smem;
+  float* slab2 = smem + cv.nA;
+  float* stat = smem + cv.body;
+  const int b0 = blockIdx.x * S;
+  const int n0 = blockIdx.y * TN;
+  const int B = p.B, Lin = p.Lin, Lout = p.Lout;
+  const int li_min = p.tap_lo - p.pad;
+
+  // ---- stage the primary source: S whole candidates, all input channels, zero halo ----
+  {
+    const int c4n = p.Cin_p >> 2;
+    const int total = S * R * c4n;
+    const bool vec = ((p.ldx & 3) == 0) && ((p.Cin & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
+    for (int idx = tid; idx < total; idx += nthr) {
+      int row = idx / c4n, c4 = idx - row * c4n;
+      int s = row / R, j = row - s * R;
+      int li = j + li_min, b = b0 + s;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b < B && li >= 0 && li < Lin) {
+        const float* src = p.x + ((size_t)b * Lin + li) * p.ldx + 4 * c4;
+        if (vec) {
+          if (4 * c4 < p.Cin) v = *(const f32x4*)src;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * c4 + e < p.Cin) v[e] = src[e];
+        }
+      }
+      *(f32x4*)&slab[row * ldA + 4 * c4] = v;
+    }
+  }
+  if (p.x2) {
+    const int c4n = p.Cin2_p >> 2;
+    const int total = S * Lout * c4n;
+    const bool vec = ((p.ldx2 & 3) == 0) && ((p.Cin2 & 3) == 0) && ((((uintptr_t)p.x2) & 15) == 0);
+    for (int idx = tid; idx < total; idx += nthr) {
+      int row = idx / c4n, c4 = idx - row * c4n;
+      int s = row / Lout, lo = row - s * Lout;
+      int b = b0 + s;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b < B) {
+        const float* src = p.x2 + ((size_t)b * Lout + lo) * p.ldx2 + 4 * c4;
+        if (vec) {
+          if (4 * c4 < p.Cin2) v = *(const f32x4*)src;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * c4 + e < p.Cin2) v[e] = src[e];
+        }
+      }
+      *(f32x4*)&slab2[row * ld2 + 4 * c4] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- prologue: GroupNorm+Mish backward of the producing Conv1dBlock, in LDS ----------
+  //   xhat = (y-mean)*rstd; z = gamma*xhat+beta; dxhat = dA*mish'(z)*gamma
+  //   dY = rstd*(dxhat - mean_g(dxhat) - xhat*mean_g(dxhat*xhat))
+  if (p.pro) {
+    const int C = p.Cin, gch = p.pro_gch;
+    const int per = Lin * C;
+    const int total = S * per;
+    for (int idx = tid; idx < total; idx += nthr) {
+      int s = idx / per, r = idx - s * per;
+      int li = r / C, c = r - li * C;
+      int b = b0 + s;
+      if (b < B) {
+        float y = p.pro_y[((size_t)b * Lin + li) * C + c];
+        const float* st = p.pro_stats + ((size_t)b * GN_GROUPS + c / gch) * 2;
+        float xh = (y - st[0]) * st[1];
+        float ga = p.pro_gamma[c];
+        float z = xh * ga + p.pro_beta[c];
+        float* e = &slab[(s * R + (li - li_min)) * ldA + c];
+        *e = *e * mish_grad_f(z) * ga;
+      }
+    }
+    __syncthreads();
+    const int cnt = Lin * gch;
+    for (int inst = wave; inst < S * GN_GROUPS; inst += nwaves) {
+      int s = inst / GN_GROUPS, gi = inst - s * GN_GROUPS;
+      int b = b0 + s;
+      float s1 = 0.f, s2 = 0.f;
+      if (b < B) {
+        const float* st = p.pro_stats + ((size_t)b * GN_GROUPS + gi) * 2;
+        float mean = st[0], rstd = st[1];
+        for (int e = lane; e < cnt; e += 64) {
+          int li = e / gch, c = gi * gch + (e - li * gch);
+          float y = p.pro_y[((size_t)b * Lin + li) * C + c];
+          float d = slab[(s * R + (li - li_min)) * ldA + c];
+          s1 += d;
+          s2 += d * ((y - mean) * rstd);
+        }
+      }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (lane == 0) {
+        stat[2 * inst] = s1 / (float)cnt;
+        stat[2 * inst + 1] = s2 / (float)cnt;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < total; idx += nthr) {
+      int s = idx / per, r = idx - s * per;
+      int li = r / C, c = r - li * C;
+      int b = b0 + s;
+      if (b < B) {
+        int gi = c / gch;
+        float y = p.pro_y[((size_t)b * Lin + li) * C + c];
+        const float* st = p.pro_stats + ((size_t)b * GN_GROUPS + gi) * 2;
+        float rstd = st[1];
+        float xh = (y - st[0]) * rstd;
+        float* e = &slab[(s * R + (li - li_min)) * ldA + c];
+        *e = rstd * (*e - stat[2 * (s * GN_GROUPS + gi)] - xh * stat[2 * (s * GN_GROUPS + gi) + 1]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- implicit GEMM on the f32 matrix cores --------------------------------------------
+  // v_mfma_f32_16x16x4_f32: lane l feeds A[row l&15][k l>>4] and B[k l>>4][col l&15].  The
+  // reduction index is permuted so that lane-group g = l>>4 owns channels 16*kk+4g .. +3 of
+  // step kk and the four MFMAs of the step consume one float4 of A (LDS) and one of B (global).
+  const int g = lane >> 4, lr = lane & 15;
+  const int ng = wave % NG, ks = wave / NG;
+  const int cbpt = p.Cin_p >> 4;
+  const int KK1 = p.ntaps * cbpt;
+  const int KK2 = p.x2 ? (p.Cin2_p >> 4) : 0;
+  const int KK = KK1 + KK2;
+  const int chunk = (KK + KS - 1) / KS;
+  const int k_begin = ks * chunk;
+  const int k_end = (k_begin + chunk < KK) ? k_begin + chunk : KK;
+  const int ncol = n0 + ng * NI * 16 + lr;
+
+  int rowA[MI], row2[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int r = mi * 16 + lr;
+    int s = r / Lout, lo = r - s * Lout;
+    bool ok = s < S;
+    rowA[mi] = ok ? (s * R + lo * p.stride) * ldA + 4 * g : 4 * g;
+    row2[mi] = ok ? (s * Lout + lo) * ld2 + 4 * g : 4 * g;
+  }
+  f32x4 acc[MI][NI], acc2[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  const float* wq = p.w + ((size_t)g * p.Npad + ncol) * 4;
+  const size_t wstep = (size_t)p.Npad * 16;     // floats per kk step
+  {
+    const int e1 = k_end < KK1 ? k_end : KK1;
+    int tau = k_begin / cbpt, cb = k_begin - tau * cbpt;
+
+    for (int kk = k_begin; kk < e1; ++kk) {
+      f32x4 a[MI], bq[NI];
+      const int aoff = tau * ldA + cb * 16;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bq[ni] = *(const f32x4*)(wq + kk * wstep + ni * 64);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], bq[ni][j], acc[mi][ni], 0, 0, 0);
+      if (++cb == cbpt) { cb = 0; ++tau; }
+    }
+    const int s2 = k_begin > KK1 ? k_begin : KK1;
+    for (int kk = s2; kk < k_end; ++kk) {
+      f32x4 a[MI], bq[NI];
+      const int aoff = (kk - KK1) * 16;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bq[ni] = *(const f32x4*)(wq + kk * wstep + ni * 64);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab2[row2[mi] + aoff];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc2[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], bq[ni][j], acc2[mi][ni], 0, 0, 0);
+    }
+  }
+  __syncthreads();     // every wave is done with the staged activations; LDS becomes the reduce buffer
+
+  // ---- split-K partials -> LDS.  C/D layout: col = lane&15, row = 4*(lane>>4) + reg -------
+  float* red = smem;
+  float* red2 = smem + cv.red1;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int o = (ks * TM + mi * 16 + g * 4 + q) * TNp + (ng * NI + ni) * 16 + lr;
+        red[o] = acc[mi][ni][q];
+        if (p.x2) red2[o] = acc2[mi][ni][q];
+      }
+  __syncthreads();
+
+  // ---- reduce over the K split, add bias; keep the tile in slot 0 ---------------------------
+  const int tile_elems = TM * TN;
+  for (int e = tid; e < tile_elems; e += nthr) {
+    int row = e / TN, col = e - row * TN;
+    int n = n0 + col;
+    float v = 0.f, v2 = 0.f;
+    for (int k = 0; k < KS; ++k) v += red[(k * TM + row) * TNp + col];
+    if (p.bias && n < p.N) v += p.bias[n];
+    red[row * TNp + col] = v;
+    if (p.x2) {
+      for (int k = 0; k < KS; ++k) v2 += red2[(k * TM + row) * TNp + col];
+      if (p.bias2 && n < p.N) v2 += p.bias2[n];
+      red2[row * TNp + col] = v2;
+    }
+    if (p.save_y) {
+      int s = row / Lout, lo = row - s * Lout;
+      int b = b0 + s;
+      if (s < S && b < B && n < p.N) p.save_y[((size_t)b * Lout + lo) * p.N + n] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- GroupNorm statistics: one wave per (candidate, group), two passes over LDS ------------
+  const int gpt = p.gn ? TN / p.gch : 0;     // groups in this column tile
+  if (p.gn) {
+    const int gch = p.gch, cnt = Lout * gch;
+    for (int inst = wave; inst < S * gpt; inst += nwaves) {
+      int s = inst / gpt, gi = inst - s * gpt;
+      float sum = 0.f;
+      for (int e = lane; e < cnt; e += 64) {
+        int lo = e / gch, c = e - lo * gch;
+        sum += red[(s * Lout + lo) * TNp + gi * gch + c];
+      }
+      float mean = wave_sum(sum) / (float)cnt;
+      float sq = 0.f;
+      for (int e = lane; e < cnt; e += 64) {
+        int lo = e / gch, c = e - lo * gch;
+        float d = red[(s * Lout + lo) * TNp + gi * gch + c] - mean;
+        sq += d * d;
+      }
+      float var = wave_sum(sq) / (float)cnt;
+      float rstd = 1.f / sqrtf(var + GN_EPS);
+      if (lane == 0) {
+        stat[2 * inst] = mean;
+        stat[2 * inst + 1] = rstd;
+        int b = b0 + s;
+        if (p.save_stats && b < B) {
+          float* o = p.save_stats + ((size_t)b * GN_GROUPS + (n0 / gch + gi)) * 2;
+          o[0] = mean;
+          o[1] = rstd;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- normalise, Mish, time bias, residuals, store ----------------------------------------------
+  for (int e = tid; e < tile_elems; e += nthr) {
+    int row = e / TN, col = e - row * TN;
+    int s = row / Lout, lo = row - s * Lout;
+    int b = b0 + s, n = n0 + col;
+    if (s >= S || b >= B || n >= p.N) continue;
+    float v = red[row * TNp + col];
+    if (p.gn) {
+      int inst = s * gpt + col / p.gch;
+      v = (v - stat[2 * inst]) * stat[2 * inst + 1] * p.gamma[n] + p.beta[n];
+      v = mish_f(v);
+    }
+    if (p.tbias) {
+      long long tt = p.t[b];
+      tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
+      v += p.tbias[(size_t)tt * p.N + n];
+    }
+    if (p.x2) v += red2[row * TNp + col];
+    if (p.res) v += p.res[((size_t)b * Lout + lo) * p.ldres + n];
+    if (p.osplit > 0) {
+      int ph = n / p.osplit, co = n - ph * p.osplit;
+      p.out[(((size_t)b * Lout + lo) * 2 + ph) * p.ldo + co] = v;
+    } else {
+      p.out[((size_t)b * Lout + lo) * p.ldo + n] = v;
+    }
+  }
+}
+
+template <int MI, int NI>
+static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st) {
+  const ConvP& p = L.p[0];
+  size_t lds = conv_lds_bytes(p, tl);
+  if (nz > 1) {
+    size_t l2 = conv_lds_bytes(L.p[1], tl);
+    if (l2 > lds) lds = l2;
+  }
+  dim3 grid((p.B + tl.S - 1) / tl.S, p.Npad / (16 * tl.NI * tl.NG), nz);
+  dim3 block(64 * tl.NG * tl.KS);
+  hipLaunchKernelGGL((conv_gemm_kernel<MI, NI>), grid, block, lds, st, L, tl.S, tl.NG, tl.KS);
+  return hipGetLastError();
+}
+
+// Dynamic LDS above 64 KiB has to be opted into per kernel (once per device, at context creation).
+hipError_t conv_init_device() {
+  hipError_t e = hipSuccess;
+#define TREBI_ATTR(mi, ni)                                                                   \
+  if (e == hipSuccess)                                                                       \
+    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni>,                           \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  TREBI_ATTR(1, 1) TREBI_ATTR(2, 1) TREBI_ATTR(4, 1) TREBI_ATTR(8, 1)
+  TREBI_ATTR(1, 2) TREBI_ATTR(2, 2) TREBI_ATTR(4, 2)
+#undef TREBI_ATTR
+  return e;
+}
+
+hipError_t launch_conv(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st) {
+#define TREBI_CASE(mi, ni) \
+  if (tl.MI == mi && tl.NI == ni) return launch_conv_t<mi, ni>(L, nz, tl, st);
+  TREBI_CASE(1, 1) TREBI_CASE(2, 1) TREBI_CASE(4, 1) TREBI_CASE(8, 1)
+  TREBI_CASE(1, 2) TREBI_CASE(2, 2) TREBI_CASE(4, 2)
+#undef TREBI_CASE
+  return hipErrorInvalidValue;
+}
+
+// ----------------------------------------------------------------------------------
+// Value head: cat([x.view(B,-1), temb]) -> Linear -> Mish -> Linear   (temporal.py:237-238)
+// One wave per candidate.  The temb columns of the first Linear are a per-timestep bias.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void head_kernel(HeadLaunch L) {
+  const HeadP& p = L.p[blockIdx.y];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* v = sm;             // [fc]
+  float* dh = sm + p.fc;     // [hd]
+  for (int i = lane; i < p.fc; i += 64) v[i] = p.v[(size_t)b * p.fc + i];
+  __syncthreads();
+  long long tt = p.t[b];
+  tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
+  float ysum = 0.f;
+  for (int j = lane; j < p.hd; j += 64) {
+    float h = p.tb[(size_t)tt * p.hd + j];
+    const float* wr = p.w1 + (size_t)j * p.fc;
+    for (int i = 0; i < p.fc; ++i) h = fmaf(wr[i], v[i], h);
+    ysum += p.w2[j] * mish_f(h);
+    dh[j] = p.w2[j] * mish_grad_f(h);
+  }
+  ysum = wave_sum(ysum);
+  if (lane == 0) p.y[b] = ysum + p.b2;
+  if (p.dv) {
+    __syncthreads();
+    for (int i = lane; i < p.fc; i += 64) {
+      float a = 0.f;
+      for (int j = 0; j < p.hd; ++j) a = fmaf(p.w1[(size_t)j * p.fc + i], dh[j], a);
+      p.dv[(size_t)b * p.fc + i] = a;
+    }
+  }
+}
+
+hipError_t launch_head(const HeadLaunch& L, int nz, hipStream_t st) {
+  const HeadP& p = L.p[0];
+  size_t lds = (size_t)(p.fc + p.hd) * sizeof(float);
+  hipLaunchKernelGGL(head_kernel, dim3(p.B, nz), dim3(64), lds, st, L);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------
+// Time-embedding tables (load time).  SinusoidalPosEmb -> Linear -> Mish -> Linear
+// (helpers.py:21-28, temporal.py:70-75), then per block Mish -> Linear (temporal.py:28-31).
+// ----------------------------------------------------------------------------------
+__global__ void time_embed_kernel(const float* w1, const float* b1, const float* w2, const float* b2,
+                                  int dim, int T, float* temb) {
+  extern __shared__ float sm[];
+  float* e = sm;             // [dim]
+  float* h = sm + dim;       // [4*dim]
+  const int t = blockIdx.x;
+  const int half = dim / 2;
+  const float sc = logf(10000.f) / (float)(half - 1);
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    float f = expf((float)i * -sc);
+    float a = (float)t * f;
+    e[i] = sinf(a);
+    e[half + i] = cosf(a);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 4 * dim; j += blockDim.x) {
+    float a = b1[j];
+    for (int i = 0; i < dim; ++i) a = fmaf(w1[j * dim + i], e[i], a);
+    h[j] = mish_f(a);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < dim; j += blockDim.x) {
+    float a = b2[j];
+    for (int i = 0; i < 4 * dim; ++i) a = fmaf(w2[j * 4 * dim + i], h[i], a);
+    temb[(size_t)t * dim + j] = a;
+  }
+}
+
+hipError_t launch_time_embed(const float* w1, const float* b1, const float* w2, const float* b2,
+                             int dim, int T, float* temb, hipStream_t st) {
+  hipLaunchKernelGGL(time_embed_kernel, dim3(T), dim3(128), (size_t)5 * dim * sizeof(float), st, w1, b1,
+                     w2, b2, dim, T, temb);
+  return hipGetLastError();
+}
+
+__global__ void time_linear_kernel(const float* w, int ldw, int col0, const float* b, const float* temb,
+                                   int dim, int T, int N, int apply_mish, float* out) {
+  const int t = blockIdx.x;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    float a = b ? b[n] : 0.f;
+    for (int i = 0; i < dim; ++i) {
+      float e = temb[(size_t)t * dim + i];
+      if (apply_mish) e = mish_f(e);
+      a = fmaf(w[(size_t)n * ldw + col0 + i], e, a);
+    }
+    out[(size_t)t * N + n] = a;
+  }
+}
+
+hipError_t launch_time_linear(const float* w, int ldw, int col0, const float* b, const float* temb,
+                              int dim, int T, int N, int apply_mish, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(time_linear_kernel, dim3(T), dim3(128), 0, st, w, ldw, col0, b, temb, dim, T, N,
+                     apply_mish, out);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------
+// Elementwise steps of the sample functions
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ bool conditioned(const StepP& s, int h, int d, int b, float* val) {
+  if (d < s.act || d >= s.act + s.obs) return false;
+  for (int k = 0; k < s.n_cond; ++k)
+    if (s.cond_index[k] == h) {
+      *val = s.cond[k][(size_t)b * s.obs + (d - s.act)];
+      return true;
+    }
+  return false;
+}
+
+// functions.py:95-119 (constrained), :21-29 (reward-only)
+__global__ void guide_update_kernel(StepP s, float* x, const float* rg, const float* cg, const float* cy,
+                                    const float* thr, const long long* t, const float* plv, int B) {
+  const size_t per = (size_t)s.H * s.D;
+  const size_t total = (size_t)B * per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int b = (int)(i / per);
+    int r = (int)(i - (size_t)b * per);
+    int h = r / s.D, d = r - h * s.D;
+    long long tt = t[b];
+    int ti = tt < 0 ? 0 : (tt >= s.T ? s.T - 1 : (int)tt);
+    float gr = rg[i];
+    if (cg) {
+      float c = cy[b], th = thr[b];
+      float over = c > th ? 1.f : 0.f;
+      if (s.guide_type == 0) {
+        float cw = (c - th) / th;
+        cw = cw < 0.f ? 0.f : (cw > 1.f ? 1.f : cw);      // NaN passes through, like torch.clamp
+        cw = s.cgw * expf(cw);
+        gr = gr - (cg[i] * cw) * over;
+      } else {
+        gr = gr - cg[i] * (s.cgw * over);
+      }
+    }
+    if (s.scale_by_std) gr = expf(plv[ti]) * gr;
+    if (s.state_mask && d >= s.act) gr = 0.f;
+    if (tt < s.t_stopgrad) gr = 0.f;
+    float v = x[i] + s.scale * gr;
+    float cvv;
+    if (conditioned(s, h, d, b, &cvv)) v = cvv;
+    x[i] = v;
+  }
+}
+
+hipError_t launch_guide_update(const StepP& s, float* x, const float* rg, const float* cg, const float* cy,
+                               const float* thr, const long long* t, const float* plv, int B,
+                               hipStream_t st) {
+  size_t total = (size_t)B * s.H * s.D;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(guide_update_kernel, dim3(blocks), dim3(256), 0, st, s, x, rg, cg, cy, thr, t, plv, B);
+  return hipGetLastError();
+}
+
+// diffusion.py:166-173, functions.py:131-137, diffusion.py:201
+__global__ void ddpm_update_kernel(StepP s, float* x, const float* x0, const float* noise,
+                                   const long long* t, const float* plv, const float* c1, const float* c2,
+                                   int B, float* chain_out) {
+  const size_t per = (size_t)s.H * s.D;
+  const size_t total = (size_t)B * per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int b = (int)(i / per);
+    int r = (int)(i - (size_t)b * per);
+    int h = r / s.D, d = r - h * s.D;
+    long long tt = t[b];
+    int ti = tt < 0 ? 0 : (tt >= s.T ? s.T - 1 : (int)tt);
+    float mean = c1[ti] * x0[i] + c2[ti] * x[i];
+    float nz = tt == 0 ? 0.f : noise[i];
+    float v = mean + expf(0.5f * plv[ti]) * nz;
+    float cvv;
+    if (conditioned(s, h, d, b, &cvv)) v = cvv;
+    x[i] = v;
+    if (chain_out) chain_out[i] = v;
+  }
+}
+
+hipError_t launch_ddpm_update(const StepP& s, float* x, const float* x0, const float* noise,
+                              const long long* t, const float* plv, const float* c1, const float* c2, int B,
+                              float* chain_out, hipStream_t st) {
+  size_t total = (size_t)B * s.H * s.D;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ddpm_update_kernel, dim3(blocks), dim3(256), 0, st, s, x, x0, noise, t, plv, c1, c2, B,
+                     chain_out);
+  return hipGetLastError();
+}
+
+// diffusion.py:192-193: x = randn(shape); apply_conditioning
+__global__ void init_x_kernel(StepP s, float* x, const float* noise0, int B, float* chain_out) {
+  const size_t per = (size_t)s.H * s.D;
+  const size_t total = (size_t)B * per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int b = (int)(i / per);
+    int r = (int)(i - (size_t)b * per);
+    int h = r / s.D, d = r - h * s.D;
+    float v = noise0[i];
+    float cvv;
+    if (conditioned(s, h, d, b, &cvv)) v = cvv;
+    x[i] = v;
+    if (chain_out) chain_out[i] = v;
+  }
+}
+
+hipError_t launch_init_x(const StepP& s, float* x, const float* noise0, int B, float* chain_out,
+                         hipStream_t st) {
+  size_t total = (size_t)B * s.H * s.D;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(init_x_kernel, dim3(blocks), dim3(256), 0, st, s, x, noise0, B, chain_out);
+  return hipGetLastError();
+}
+
+__global__ void fill_t_kernel(long long* t, int B, int value) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) t[i] = value;
+}
+hipError_t launch_fill_t(long long* t, int B, int value, hipStream_t st) {
+  int blocks = (B + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fill_t_kernel, dim3(blocks), dim3(256), 0, st, t, B, value);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------
+// Selection (functions.py:126-129, diffusion.py:44-62)
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void feasibility_kernel(const float* ry, const float* cy,
+                                                           const float* thr, int n, float* out) {
+  __shared__ int any_feasible;
+  if (threadIdx.x == 0) any_feasible = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) mine |= (cy[i] <= thr[i]) ? 1 : 0;
+  if (mine) any_feasible = 1;      // benign race: every writer stores 1
+  __syncthreads();
+  const int feas = any_feasible;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float c = cy[i];
+    out[i] = feas ? (c > thr[i] ? ry[i] - 1e8f : ry[i]) : -c;
+  }
+}
+hipError_t launch_feasibility(const float* ry, const float* cy, const float* thr, int n, float* out,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(feasibility_kernel, dim3(1), dim3(1024), 0, st, ry, cy, thr, n, out);
+  return hipGetLastError();
+}
+
+// Descending rank by counting: rank(i) = #{j : v[j] > v[i] or (v[j] == v[i] and j < i)}.
+// NaNs compare false everywhere, so they are ordered among themselves by index after every number.
+__global__ __launch_bounds__(256) void argsort_desc_kernel(const float* v, int n, long long* order) {
+  __shared__ float tile[256];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float vi = i < n ? v[i] : 0.f;
+  const bool nan_i = vi != vi;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    int j = j0 + threadIdx.x;
+    tile[threadIdx.x] = j < n ? v[j] : 0.f;
+    __syncthreads();
+    int m = n - j0 < 256 ? n - j0 : 256;
+    for (int k = 0; k < m; ++k) {
+      float vj = tile[k];
+      int jj = j0 + k;
+      bool nan_j = vj != vj;
+      bool before = nan_i ? (!nan_j || jj < i) : (!nan_j && (vj > vi || (vj == vi && jj < i)));
+      rank += before ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (i < n) order[rank] = i;
+}
+hipError_t launch_argsort_desc(const float* v, int n, long long* order, hipStream_t st) {
+  hipLaunchKernelGGL(argsort_desc_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v, n, order);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void group_argmax_kernel(const float* v, int per, long long* best) {
+  const int gidx = blockIdx.x, lane = threadIdx.x;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lane; i < per; i += 64) {
+    float x = v[(size_t)gidx * per + i];
+    if (x > bv || (x == bv && i < bi) || bi == 0x7fffffff) { bv = x; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(bv, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) best[gidx] = (long long)gidx * per + bi;
+}
+hipError_t launch_group_argmax(const float* v, int ng, int per, long long* best, hipStream_t st) {
+  hipLaunchKernelGGL(group_argmax_kernel, dim3(ng), dim3(64), 0, st, v, per, best);
+  return hipGetLastError();
+}
+
+}  // namespace trebi

@@ -1,0 +1,1401 @@
+// Host side of libtrebi_hip.so: architecture plans, weight packing, op scheduling, the
+// captured sampling loop and the extern "C" boundary declared in include/trebi_hip.h.
+//
+// Nothing here computes on the CPU: the host only lays weights out for the kernels
+// (pure permutation / zero padding), sizes tiles, and enqueues launches.
+#include "common.h"
+#include "../../include/trebi_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace trebi;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fail(TREBI_HIP_ERROR, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                  __FILE__, __LINE__);                                                        \
+  } while (0)
+
+struct Unsupported {
+  std::string msg;
+};
+static void unsupported(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw Unsupported{buf};
+}
+struct BadShape {
+  std::string msg;
+};
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+struct trebi_ctx {
+  int device;
+};
+
+// ------------------------------------------------------------------------------------
+// plan data structures
+// ------------------------------------------------------------------------------------
+namespace {
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct BufRef {            // a [B, L, C] view: workspace buffer (id >= 0) or one of the call's tensors
+  int id = -100;           // -100: none
+  int ld = 0;              // row stride in floats (0: taken from the binding for external tensors)
+  int coloff = 0;
+};
+constexpr int EXT_X = -1, EXT_OUT = -2, EXT_GRAD = -3, NONE = -100;
+
+struct GnW {
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  int gch = 0;
+};
+
+struct Op {
+  int kind = 0;            // 0 conv, 1 head
+  std::string name;
+  int Lin = 0, Lout = 0, stride = 1, pad = 0, tap_lo = 0, ntaps = 1;
+  int Cin = 0, Cin_p = 0, Cin2 = 0, Cin2_p = 0, N = 0, Npad = 0, osplit = 0;
+  const float* w = nullptr;
+  const float* bias = nullptr;
+  const float* bias2 = nullptr;
+  bool gn = false;
+  GnW gnw;
+  const float* tbias = nullptr;
+  BufRef src, src2, dst, res;
+  int save_y = NONE, save_st = NONE;
+  bool pro = false;
+  GnW pro_gn;
+  int pro_y = NONE, pro_st = NONE;
+  double flops = 0;        // algorithmic (zero-padding taps excluded), per candidate
+  // head
+  int v_buf = NONE, dv_buf = NONE;
+};
+
+struct Binding {
+  const float* x = nullptr;
+  int ldx = 0;
+  float* out = nullptr;
+  int ldo = 0;
+  float* grad = nullptr;
+  int ldg = 0;
+  const long long* t = nullptr;
+  float* ws = nullptr;
+  float* y = nullptr;      // head output
+};
+
+}  // namespace
+
+struct trebi_net {
+  trebi_ctx* ctx = nullptr;
+  trebi_net_desc desc{};
+  int T = 0;
+  std::vector<void*> allocs;                       // device allocations owned by the net
+  std::vector<size_t> buf_per_sample;              // workspace buffers, floats per candidate
+  std::vector<Op> fwd, bwd;
+  // head
+  const float* head_w1 = nullptr;
+  const float* head_tb = nullptr;
+  const float* head_w2 = nullptr;
+  float head_b2 = 0.f;
+  int fc = 0, hd = 0;
+  double flops_fwd = 0, flops_bwd = 0;
+
+  ~trebi_net() {
+    for (void* p : allocs) (void)hipFree(p);
+  }
+  int new_buf(size_t per_sample) {
+    buf_per_sample.push_back(per_sample);
+    return (int)buf_per_sample.size() - 1;
+  }
+  size_t ws_floats(int B) const {
+    size_t n = 0;
+    for (size_t s : buf_per_sample) n += (s * (size_t)B + 63) / 64 * 64;
+    return n;
+  }
+  std::vector<size_t> offsets(int B) const {
+    std::vector<size_t> o(buf_per_sample.size());
+    size_t n = 0;
+    for (size_t i = 0; i < o.size(); ++i) {
+      o[i] = n;
+      n += (buf_per_sample[i] * (size_t)B + 63) / 64 * 64;
+    }
+    return o;
+  }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// expected parameter table (mirrors trebi_amd/spec.py; reference temporal.py:18-46,49-118,153-211)
+// ------------------------------------------------------------------------------------
+struct ParamSpec {
+  std::string name;
+  int64_t numel;
+};
+
+struct ArchPlan {
+  // unet
+  struct Lvl { int cin, cout, L; bool down; };
+  std::vector<Lvl> downs;
+  int mid_c = 0, mid_L = 0;
+  struct Up { int cin, cout, L; bool up; };
+  std::vector<Up> ups;
+  int final_L = 0;
+  // value
+  struct VB { int cin, cout, L; };
+  std::vector<VB> blocks;
+  VB mid1{}, mid2{};
+  int vfinal_L = 0, c3 = 0, fc_dim = 0;
+};
+
+int down_len(int L) { return (L + 2 - 3) / 2 + 1; }
+
+ArchPlan make_arch(const trebi_net_desc& d) {
+  ArchPlan a;
+  std::vector<int> dims{d.transition_dim};
+  for (int i = 0; i < d.n_mults; ++i) dims.push_back(d.dim * d.dim_mults[i]);
+  int n = d.n_mults;
+  if (d.kind == 0) {
+    std::vector<int> hist;
+    int h = d.horizon;
+    for (int i = 0; i < n; ++i) {
+      hist.push_back(h);
+      bool last = i >= n - 1;
+      a.downs.push_back({dims[i], dims[i + 1], h, !last});
+      if (!last) h = std::max(h / 2, 1);
+    }
+    a.mid_c = dims[n];
+    a.mid_L = h;
+    for (int k = 0; k < n - 1; ++k) {
+      int j = n - 1 - k;                                  // level whose skip is popped
+      bool up = hist[n - 1 - k] != hist[n - 2 - k];
+      a.ups.push_back({dims[j + 1] * 2, dims[j], h, up});
+      h = hist[n - 2 - k];
+    }
+    a.final_L = h;
+  } else {
+    int L = d.horizon, h = d.horizon;
+    for (int i = 0; i < n; ++i) {
+      a.blocks.push_back({dims[i], dims[i + 1], L});
+      L = down_len(L);
+      if (!(i >= n - 1)) h = h / 2;
+    }
+    int c = dims[n];
+    a.mid1 = {c, c / 2, L};
+    L = down_len(L);
+    h /= 2;
+    a.mid2 = {c / 2, c / 4, L};
+    L = down_len(L);
+    h /= 2;
+    a.vfinal_L = L;
+    a.c3 = c / 4;
+    a.fc_dim = a.c3 * std::max(h, 1);
+  }
+  return a;
+}
+
+void spec_resblock(std::vector<ParamSpec>& s, const std::string& p, int cin, int cout, int dim) {
+  int cc[2][2] = {{cin, cout}, {cout, cout}};
+  for (int j = 0; j < 2; ++j) {
+    std::string q = p + ".blocks." + std::to_string(j) + ".block";
+    s.push_back({q + ".0.weight", (int64_t)cc[j][1] * cc[j][0] * 5});
+    s.push_back({q + ".0.bias", cc[j][1]});
+    s.push_back({q + ".2.weight", cc[j][1]});
+    s.push_back({q + ".2.bias", cc[j][1]});
+  }
+  s.push_back({p + ".time_mlp.1.weight", (int64_t)cout * dim});
+  s.push_back({p + ".time_mlp.1.bias", cout});
+  if (cin != cout) {
+    s.push_back({p + ".residual_conv.weight", (int64_t)cout * cin});
+    s.push_back({p + ".residual_conv.bias", cout});
+  }
+}
+
+std::vector<ParamSpec> param_specs(const trebi_net_desc& d) {
+  ArchPlan a = make_arch(d);
+  std::vector<ParamSpec> s;
+  int dim = d.dim;
+  s.push_back({"time_mlp.1.weight", (int64_t)4 * dim * dim});
+  s.push_back({"time_mlp.1.bias", 4 * dim});
+  s.push_back({"time_mlp.3.weight", (int64_t)4 * dim * dim});
+  s.push_back({"time_mlp.3.bias", dim});
+  auto S = [](int i) { return std::to_string(i); };
+  if (d.kind == 0) {
+    for (size_t i = 0; i < a.downs.size(); ++i) {
+      auto& l = a.downs[i];
+      spec_resblock(s, "downs." + S(i) + ".0", l.cin, l.cout, dim);
+      spec_resblock(s, "downs." + S(i) + ".1", l.cout, l.cout, dim);
+      if (l.down) {
+        s.push_back({"downs." + S(i) + ".3.conv.weight", (int64_t)l.cout * l.cout * 3});
+        s.push_back({"downs." + S(i) + ".3.conv.bias", l.cout});
+      }
+    }
+    for (size_t i = 0; i < a.ups.size(); ++i) {
+      auto& u = a.ups[i];
+      spec_resblock(s, "ups." + S(i) + ".0", u.cin, u.cout, dim);
+      spec_resblock(s, "ups." + S(i) + ".1", u.cout, u.cout, dim);
+      if (u.up) {
+        s.push_back({"ups." + S(i) + ".3.conv.weight", (int64_t)u.cout * u.cout * 4});
+        s.push_back({"ups." + S(i) + ".3.conv.bias", u.cout});
+      }
+    }
+    spec_resblock(s, "mid_block1", a.mid_c, a.mid_c, dim);
+    spec_resblock(s, "mid_block2", a.mid_c, a.mid_c, dim);
+    s.push_back({"final_conv.0.block.0.weight", (int64_t)dim * dim * 5});
+    s.push_back({"final_conv.0.block.0.bias", dim});
+    s.push_back({"final_conv.0.block.2.weight", dim});
+    s.push_back({"final_conv.0.block.2.bias", dim});
+    s.push_back({"final_conv.1.weight", (int64_t)d.transition_dim * dim});
+    s.push_back({"final_conv.1.bias", d.transition_dim});
+  } else {
+    for (size_t i = 0; i < a.blocks.size(); ++i) {
+      auto& b = a.blocks[i];
+      spec_resblock(s, "blocks." + S(i) + ".0", b.cin, b.cout, dim);
+      spec_resblock(s, "blocks." + S(i) + ".1", b.cout, b.cout, dim);
+      s.push_back({"blocks." + S(i) + ".2.conv.weight", (int64_t)b.cout * b.cout * 3});
+      s.push_back({"blocks." + S(i) + ".2.conv.bias", b.cout});
+    }
+    spec_resblock(s, "mid_block1", a.mid1.cin, a.mid1.cout, dim);
+    s.push_back({"mid_down1.conv.weight", (int64_t)a.mid1.cout * a.mid1.cout * 3});
+    s.push_back({"mid_down1.conv.bias", a.mid1.cout});
+    spec_resblock(s, "mid_block2", a.mid2.cin, a.mid2.cout, dim);
+    s.push_back({"mid_down2.conv.weight", (int64_t)a.mid2.cout * a.mid2.cout * 3});
+    s.push_back({"mid_down2.conv.bias", a.mid2.cout});
+    int fc = a.fc_dim;
+    s.push_back({"final_block.0.weight", (int64_t)(fc / 2) * (fc + dim)});
+    s.push_back({"final_block.0.bias", fc / 2});
+    s.push_back({"final_block.2.weight", fc / 2});
+    s.push_back({"final_block.2.bias", 1});
+  }
+  return s;
+}
+
+int check_desc(const trebi_net_desc* d) {
+  if (!d) return fail(TREBI_BAD_ARG, "null descriptor");
+  if (d->kind != 0 && d->kind != 1) return fail(TREBI_BAD_ARG, "kind must be 0 (TemporalUnet) or 1 (ValueFunction)");
+  if (d->n_mults < 1 || d->n_mults > 8) return fail(TREBI_BAD_ARG, "n_mults must be in 1..8");
+  if (d->horizon < 1 || d->transition_dim < 1 || d->dim < 8 || d->max_timesteps < 1)
+    return fail(TREBI_BAD_ARG, "horizon, transition_dim, max_timesteps must be >= 1 and dim >= 8");
+  if (d->dim % 8) return fail(TREBI_UNSUPPORTED_CONFIG, "dim must be a multiple of 8 (GroupNorm(8))");
+  for (int i = 0; i < d->n_mults; ++i)
+    if (d->dim_mults[i] < 1) return fail(TREBI_BAD_ARG, "dim_mults must be positive");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// builder: uploads packed weights and emits ops
+// ------------------------------------------------------------------------------------
+struct Builder {
+  trebi_net* net;
+  std::unordered_map<std::string, std::pair<const float*, int64_t>> sd;
+  int dim, T;
+  const float* temb = nullptr;      // device [T, dim]
+
+  const float* host(const std::string& name, int64_t numel) {
+    auto it = sd.find(name);
+    if (it == sd.end()) throw BadShape{"missing tensor '" + name + "'"};
+    if (it->second.second != numel)
+      throw BadShape{"tensor '" + name + "' has " + std::to_string(it->second.second) + " elements, expected " +
+                     std::to_string(numel)};
+    return it->second.first;
+  }
+  float* dalloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)) != hipSuccess) throw BadShape{"hipMalloc failed"};
+    net->allocs.push_back(p);
+    return (float*)p;
+  }
+  const float* upload(const float* h, size_t n) {
+    float* d = dalloc(n);
+    if (hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) throw BadShape{"hipMemcpy failed"};
+    return d;
+  }
+  const float* upload(const std::vector<float>& v) { return upload(v.data(), v.size()); }
+
+  // Weff is [ntaps][Cin][N] (+ optional second source [Cin2][N]); pack to the kernel's
+  // [(ntaps*Cin_p + Cin2_p)/16][4][Npad][4] order (pure permutation + zero fill).
+  const float* pack(const std::vector<float>& Weff, int ntaps, int Cin, int N, const std::vector<float>* W2,
+                    int Cin2) {
+    int Cin_p = rup(Cin, 16), Cin2_p = W2 ? rup(Cin2, 16) : 0, Npad = rup(N, 16);
+    int KK = (ntaps * Cin_p + Cin2_p) / 16;
+    std::vector<float> P((size_t)KK * 16 * Npad, 0.f);
+    auto put = [&](int kk, int cc, int n, float v) {   // cc in [0,16)
+      int g = cc >> 2, j = cc & 3;
+      P[(((size_t)kk * 4 + g) * Npad + n) * 4 + j] = v;
+    };
+    for (int tp = 0; tp < ntaps; ++tp)
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int n = 0; n < N; ++n)
+          put(tp * (Cin_p / 16) + ci / 16, ci % 16, n, Weff[((size_t)tp * Cin + ci) * N + n]);
+    if (W2)
+      for (int ci = 0; ci < Cin2; ++ci)
+        for (int n = 0; n < N; ++n)
+          put(ntaps * (Cin_p / 16) + ci / 16, ci % 16, n, (*W2)[(size_t)ci * N + n]);
+    return upload(P);
+  }
+
+  static void tap_range(int Lin, int Lout, int stride, int pad, int k, int* lo, int* hi) {
+    *lo = k;
+    *hi = -1;
+    for (int tp = 0; tp < k; ++tp) {
+      bool any = false;
+      for (int o = 0; o < Lout && !any; ++o) {
+        int li = o * stride + tp - pad;
+        any = li >= 0 && li < Lin;
+      }
+      if (any) {
+        *lo = std::min(*lo, tp);
+        *hi = std::max(*hi, tp);
+      }
+    }
+  }
+  static double valid_pairs(int Lin, int Lout, int stride, int pad, int tlo, int nt) {
+    double c = 0;
+    for (int tp = tlo; tp < tlo + nt; ++tp)
+      for (int o = 0; o < Lout; ++o) {
+        int li = o * stride + tp - pad;
+        if (li >= 0 && li < Lin) c += 1;
+      }
+    return c;
+  }
+
+  GnW gn_weights(const std::string& p, int C) {
+    GnW g;
+    g.gamma = upload(host(p + ".weight", C), C);
+    g.beta = upload(host(p + ".bias", C), C);
+    g.gch = C / GN_GROUPS;
+    return g;
+  }
+
+  const float* time_table(const std::string& wname, const std::string& bname, int N, int ldw, int col0,
+                          bool mish) {
+    const float* w = upload(host(wname, (int64_t)N * ldw), (size_t)N * ldw);
+    const float* b = upload(host(bname, N), N);
+    float* out = dalloc((size_t)T * N);
+    if (launch_time_linear(w, ldw, col0, b, temb, dim, T, N, mish ? 1 : 0, out, 0) != hipSuccess)
+      throw BadShape{"time table kernel launch failed"};
+    return out;
+  }
+
+  void finish_geom(Op& op, int Cin, int Cin2, int N) {
+    op.Cin = Cin;
+    op.Cin_p = rup(Cin, 16);
+    op.Cin2 = Cin2;
+    op.Cin2_p = Cin2 ? rup(Cin2, 16) : 0;
+    op.N = N;
+    op.Npad = rup(N, 16);
+  }
+
+  // ---- forward convolutions ----------------------------------------------------------
+  // Conv1d(Cin, Cout, k, stride, pad) from a reference [Cout, Cin, k] tensor.
+  Op conv_fwd(const std::string& wname, int Cin, int Cout, int k, int stride, int pad, int Lin,
+              const std::string* res_wname, int Cres) {
+    Op op;
+    op.name = wname;
+    op.Lin = Lin;
+    op.Lout = (Lin + 2 * pad - k) / stride + 1;
+    op.stride = stride;
+    op.pad = pad;
+    int lo, hi;
+    tap_range(Lin, op.Lout, stride, pad, k, &lo, &hi);
+    op.tap_lo = lo;
+    op.ntaps = hi - lo + 1;
+    const float* w = host(wname + ".weight", (int64_t)Cout * Cin * k);
+    std::vector<float> W((size_t)op.ntaps * Cin * Cout);
+    for (int tp = 0; tp < op.ntaps; ++tp)
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int co = 0; co < Cout; ++co)
+          W[((size_t)tp * Cin + ci) * Cout + co] = w[((size_t)co * Cin + ci) * k + lo + tp];
+    std::vector<float> W2;
+    if (res_wname) {
+      const float* r = host(*res_wname + ".weight", (int64_t)Cout * Cres);
+      W2.resize((size_t)Cres * Cout);
+      for (int ci = 0; ci < Cres; ++ci)
+        for (int co = 0; co < Cout; ++co) W2[(size_t)ci * Cout + co] = r[(size_t)co * Cres + ci];
+      op.bias2 = upload(host(*res_wname + ".bias", Cout), Cout);
+    }
+    finish_geom(op, Cin, res_wname ? Cres : 0, Cout);
+    op.w = pack(W, op.ntaps, Cin, Cout, res_wname ? &W2 : nullptr, Cres);
+    op.bias = upload(host(wname + ".bias", Cout), Cout);
+    op.flops = 2.0 * Cin * Cout * valid_pairs(Lin, op.Lout, stride, pad, lo, op.ntaps) +
+               (res_wname ? 2.0 * Cres * Cout * op.Lout : 0.0);
+    return op;
+  }
+
+  // ConvTranspose1d(C, C, 4, 2, 1) [Cin, Cout, 4] as a k=3 / pad=1 convolution producing the two
+  // output phases side by side: out[2j]   = x[j-1] W[..3] + x[j] W[..1]
+  //                             out[2j+1] = x[j]   W[..2] + x[j+1] W[..0]
+  Op convT_fwd(const std::string& wname, int C, int Lin) {
+    Op op;
+    op.name = wname;
+    op.Lin = Lin;
+    op.Lout = Lin;
+    op.stride = 1;
+    op.pad = 1;
+    int lo, hi;
+    tap_range(Lin, Lin, 1, 1, 3, &lo, &hi);
+    op.tap_lo = lo;
+    op.ntaps = hi - lo + 1;
+    const float* w = host(wname + ".weight", (int64_t)C * C * 4);
+    const float* b = host(wname + ".bias", C);
+    int N = 2 * C;
+    std::vector<float> W((size_t)op.ntaps * C * N, 0.f);
+    const int ktab[3][2] = {{3, -1}, {1, 2}, {-1, 0}};      // [tap][phase] -> transposed-conv tap
+    double pairs = 0;
+    for (int tp = 0; tp < op.ntaps; ++tp)
+      for (int ph = 0; ph < 2; ++ph) {
+        int kt = ktab[lo + tp][ph];
+        if (kt < 0) continue;
+        for (int o = 0; o < Lin; ++o) {
+          int li = o + lo + tp - 1;
+          if (li >= 0 && li < Lin) pairs += 1;
+        }
+        for (int ci = 0; ci < C; ++ci)
+          for (int co = 0; co < C; ++co)
+            W[((size_t)tp * C + ci) * N + ph * C + co] = w[((size_t)ci * C + co) * 4 + kt];
+      }
+    std::vector<float> bb(N);
+    for (int i = 0; i < N; ++i) bb[i] = b[i % C];
+    finish_geom(op, C, 0, N);
+    op.osplit = C;
+    op.w = pack(W, op.ntaps, C, N, nullptr, 0);
+    op.bias = upload(bb);
+    op.flops = 2.0 * C * C * pairs;
+    return op;
+  }
+
+  // ---- input-gradient convolutions (ValueFunction backward) ---------------------------
+  // dX = conv(dY, flip(W)^T): K = (tap', Cout), N = Cin.  Stride-1, pad = k/2.
+  Op conv_dgrad(const std::string& wname, int Cin, int Cout, int k, int L, const std::string* res_wname) {
+    Op op;
+    op.name = wname + " (dgrad)";
+    op.Lin = L;
+    op.Lout = L;
+    op.stride = 1;
+    op.pad = k / 2;
+    int lo, hi;
+    tap_range(L, L, 1, k / 2, k, &lo, &hi);
+    op.tap_lo = lo;
+    op.ntaps = hi - lo + 1;
+    const float* w = host(wname + ".weight", (int64_t)Cout * Cin * k);
+    std::vector<float> W((size_t)op.ntaps * Cout * Cin);
+    for (int tp = 0; tp < op.ntaps; ++tp)
+      for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+          W[((size_t)tp * Cout + co) * Cin + ci] = w[((size_t)co * Cin + ci) * k + (k - 1 - (lo + tp))];
+    std::vector<float> W2;
+    int C2 = 0;
+    if (res_wname) {                  // residual 1x1 conv [Cout2, Cin, 1]: dX += dOut @ Wr
+      auto it = sd.find(*res_wname + ".weight");
+      if (it == sd.end()) throw BadShape{"missing tensor '" + *res_wname + ".weight'"};
+      C2 = (int)(it->second.second / Cin);
+      const float* r = host(*res_wname + ".weight", (int64_t)C2 * Cin);
+      W2.resize((size_t)C2 * Cin);
+      for (int co = 0; co < C2; ++co)
+        for (int ci = 0; ci < Cin; ++ci) W2[(size_t)co * Cin + ci] = r[(size_t)co * Cin + ci];
+    }
+    finish_geom(op, Cout, C2, Cin);
+    op.w = pack(W, op.ntaps, Cout, Cin, res_wname ? &W2 : nullptr, C2);
+    op.flops = 2.0 * Cin * Cout * valid_pairs(L, L, 1, k / 2, lo, op.ntaps) + 2.0 * C2 * Cin * L;
+    return op;
+  }
+
+  // Backward-to-input of Downsample1d = Conv1d(C, C, 3, 2, 1): with Lin even,
+  //   dX[2j]   = dY[j] W[..1]^T,   dX[2j+1] = dY[j] W[..2]^T + dY[j+1] W[..0]^T
+  // i.e. a 2-tap convolution over dY producing both phases side by side; Lin == 1 is a 1x1.
+  Op down_dgrad(const std::string& wname, int C, int Lin_fwd) {
+    Op op;
+    op.name = wname + " (dgrad)";
+    int Lo = down_len(Lin_fwd);
+    const float* w = host(wname + ".weight", (int64_t)C * C * 3);
+    if (Lin_fwd == 1) {
+      op.Lin = op.Lout = 1;
+      op.stride = 1;
+      op.pad = 0;
+      op.tap_lo = 0;
+      op.ntaps = 1;
+      std::vector<float> W((size_t)C * C);
+      for (int co = 0; co < C; ++co)
+        for (int ci = 0; ci < C; ++ci) W[(size_t)co * C + ci] = w[((size_t)co * C + ci) * 3 + 1];
+      finish_geom(op, C, 0, C);
+      op.w = pack(W, 1, C, C, nullptr, 0);
+      op.flops = 2.0 * C * C;
+      return op;
+    }
+    if (Lin_fwd % 2) unsupported("Downsample1d backward needs an even (or unit) length, got %d", Lin_fwd);
+    op.Lin = op.Lout = Lo;
+    op.stride = 1;
+    op.pad = 0;
+    int lo, hi;
+    tap_range(Lo, Lo, 1, 0, 2, &lo, &hi);
+    op.tap_lo = lo;
+    op.ntaps = hi - lo + 1;
+    int N = 2 * C;
+    std::vector<float> W((size_t)op.ntaps * C * N, 0.f);
+    const int ktab[2][2] = {{1, 2}, {-1, 0}};           // [tap][phase] -> forward tap
+    double pairs = 0;
+    for (int tp = 0; tp < op.ntaps; ++tp)
+      for (int ph = 0; ph < 2; ++ph) {
+        int kt = ktab[lo + tp][ph];
+        if (kt < 0) continue;
+        for (int o = 0; o < Lo; ++o)
+          if (o + lo + tp < Lo) pairs += 1;
+        for (int co = 0; co < C; ++co)
+          for (int ci = 0; ci < C; ++ci)
+            W[((size_t)tp * C + co) * N + ph * C + ci] = w[((size_t)co * C + ci) * 3 + kt];
+      }
+    finish_geom(op, C, 0, N);
+    op.osplit = C;
+    op.w = pack(W, op.ntaps, C, N, nullptr, 0);
+    op.flops = 2.0 * C * C * pairs;
+    return op;
+  }
+
+  // ---- ResidualTemporalBlock (temporal.py:18-46) -----------------------------------------
+  struct RBRec {
+    std::string prefix;
+    int cin, cout, L;
+    bool has_res;
+    int y0, st0, y1, st1;
+    GnW gn0, gn1;
+  };
+
+  RBRec res_block(const std::string& p, BufRef src, int cin, int cout, int L, BufRef dst, bool save) {
+    RBRec rec{p, cin, cout, L, cin != cout, NONE, NONE, NONE, NONE, {}, {}};
+    std::string b0 = p + ".blocks.0.block", b1 = p + ".blocks.1.block";
+    Op o0 = conv_fwd(b0 + ".0", cin, cout, 5, 1, 2, L, nullptr, 0);
+    o0.gn = true;
+    o0.gnw = rec.gn0 = gn_weights(b0 + ".2", cout);
+    o0.tbias = time_table(p + ".time_mlp.1.weight", p + ".time_mlp.1.bias", cout, dim, 0, true);
+    o0.src = src;
+    int a0 = net->new_buf((size_t)L * cout);
+    o0.dst = {a0, cout, 0};
+    std::string rname = p + ".residual_conv";
+    Op o1 = conv_fwd(b1 + ".0", cout, cout, 5, 1, 2, L, rec.has_res ? &rname : nullptr, cin);
+    o1.gn = true;
+    o1.gnw = rec.gn1 = gn_weights(b1 + ".2", cout);
+    o1.src = {a0, cout, 0};
+    if (rec.has_res) o1.src2 = src; else o1.res = src;
+    o1.dst = dst;
+    if (save) {
+      o0.save_y = rec.y0 = net->new_buf((size_t)L * cout);
+      o0.save_st = rec.st0 = net->new_buf(2 * GN_GROUPS);
+      o1.save_y = rec.y1 = net->new_buf((size_t)L * cout);
+      o1.save_st = rec.st1 = net->new_buf(2 * GN_GROUPS);
+    }
+    net->fwd.push_back(o0);
+    net->fwd.push_back(o1);
+    return rec;
+  }
+
+  // backward-to-input of a block: g = dL/d(out) [L, cout] -> dst = dL/d(in) [L, cin]
+  void res_block_bwd(const RBRec& r, BufRef g, BufRef dst) {
+    std::string b0 = r.prefix + ".blocks.0.block", b1 = r.prefix + ".blocks.1.block";
+    Op kb = conv_dgrad(b1 + ".0", r.cout, r.cout, 5, r.L, nullptr);
+    kb.src = g;
+    kb.pro = true;
+    kb.pro_gn = r.gn1;
+    kb.pro_y = r.y1;
+    kb.pro_st = r.st1;
+    int da0 = net->new_buf((size_t)r.L * r.cout);
+    kb.dst = {da0, r.cout, 0};
+    std::string rname = r.prefix + ".residual_conv";
+    Op kc = conv_dgrad(b0 + ".0", r.cin, r.cout, 5, r.L, r.has_res ? &rname : nullptr);
+    kc.src = {da0, r.cout, 0};
+    kc.pro = true;
+    kc.pro_gn = r.gn0;
+    kc.pro_y = r.y0;
+    kc.pro_st = r.st0;
+    if (r.has_res) kc.src2 = g; else kc.res = g;
+    kc.dst = dst;
+    net->bwd.push_back(kb);
+    net->bwd.push_back(kc);
+  }
+};
+
+void build_unet(Builder& B, const ArchPlan& a) {
+  trebi_net* net = B.net;
+  const trebi_net_desc& d = net->desc;
+  int n = d.n_mults;
+  auto S = [](int i) { return std::to_string(i); };
+  std::vector<int> C(n), L(n), cat(n, NONE);
+  for (int i = 0; i < n; ++i) {
+    C[i] = a.downs[i].cout;
+    L[i] = a.downs[i].L;
+    if (i >= 1) cat[i] = net->new_buf((size_t)L[i] * 2 * C[i]);
+  }
+  BufRef cur{EXT_X, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    int rA = net->new_buf((size_t)L[i] * C[i]);
+    B.res_block("downs." + S(i) + ".0", cur, a.downs[i].cin, C[i], L[i], {rA, C[i], 0}, false);
+    BufRef skip = i >= 1 ? BufRef{cat[i], 2 * C[i], C[i]} : BufRef{net->new_buf((size_t)L[i] * C[i]), C[i], 0};
+    B.res_block("downs." + S(i) + ".1", {rA, C[i], 0}, C[i], C[i], L[i], skip, false);
+    cur = skip;
+    if (a.downs[i].down) {
+      Op dn = B.conv_fwd("downs." + S(i) + ".3.conv", C[i], C[i], 3, 2, 1, L[i], nullptr, 0);
+      dn.src = cur;
+      int db = net->new_buf((size_t)dn.Lout * C[i]);
+      dn.dst = {db, C[i], 0};
+      net->fwd.push_back(dn);
+      cur = {db, C[i], 0};
+    }
+  }
+  int Lm = a.mid_L, Cm = a.mid_c;
+  int m1 = net->new_buf((size_t)Lm * Cm);
+  B.res_block("mid_block1", cur, Cm, Cm, Lm, {m1, Cm, 0}, false);
+  if (n == 1) {
+    int m2 = net->new_buf((size_t)Lm * Cm);
+    B.res_block("mid_block2", {m1, Cm, 0}, Cm, Cm, Lm, {m2, Cm, 0}, false);
+    cur = {m2, Cm, 0};
+  } else {
+    B.res_block("mid_block2", {m1, Cm, 0}, Cm, Cm, Lm, {cat[n - 1], 2 * C[n - 1], 0}, false);
+  }
+  for (int k = 0; k < n - 1; ++k) {
+    int j = n - 1 - k;
+    const auto& u = a.ups[k];
+    int Lj = u.L;
+    if (Lj != L[j]) unsupported("TemporalUnet skip length mismatch at level %d (%d vs %d)", j, Lj, L[j]);
+    int u0 = net->new_buf((size_t)Lj * u.cout);
+    B.res_block("ups." + S(k) + ".0", {cat[j], 2 * C[j], 0}, u.cin, u.cout, Lj, {u0, u.cout, 0}, false);
+    int Lnext = u.up ? 2 * Lj : Lj;
+    if (j - 1 >= 0 && Lnext != L[j - 1])
+      unsupported("TemporalUnet up-path length %d does not match skip length %d", Lnext, L[j - 1]);
+    BufRef nextdst = (j - 1 >= 1) ? BufRef{cat[j - 1], 2 * C[j - 1], 0}
+                                  : BufRef{net->new_buf((size_t)Lnext * u.cout), u.cout, 0};
+    if (u.up) {
+      int u1 = net->new_buf((size_t)Lj * u.cout);
+      B.res_block("ups." + S(k) + ".1", {u0, u.cout, 0}, u.cout, u.cout, Lj, {u1, u.cout, 0}, false);
+      Op up = B.convT_fwd("ups." + S(k) + ".3.conv", u.cout, Lj);
+      up.src = {u1, u.cout, 0};
+      up.dst = nextdst;
+      net->fwd.push_back(up);
+    } else {
+      B.res_block("ups." + S(k) + ".1", {u0, u.cout, 0}, u.cout, u.cout, Lj, nextdst, false);
+    }
+    cur = nextdst;
+  }
+  // final_conv: Conv1dBlock(dim, dim, 5) then Conv1d(dim, out, 1)   (temporal.py:115-118)
+  int Lf = a.final_L, dim = d.dim;
+  Op f0 = B.conv_fwd("final_conv.0.block.0", dim, dim, 5, 1, 2, Lf, nullptr, 0);
+  f0.gn = true;
+  f0.gnw = B.gn_weights("final_conv.0.block.2", dim);
+  f0.src = cur;
+  int fb = net->new_buf((size_t)Lf * dim);
+  f0.dst = {fb, dim, 0};
+  net->fwd.push_back(f0);
+  Op f1 = B.conv_fwd("final_conv.1", dim, d.transition_dim, 1, 1, 0, Lf, nullptr, 0);
+  f1.src = {fb, dim, 0};
+  f1.dst = {EXT_OUT, 0, 0};
+  net->fwd.push_back(f1);
+  if (Lf != d.horizon) unsupported("TemporalUnet output length %d != horizon %d", Lf, d.horizon);
+}
+
+void build_value(Builder& B, const ArchPlan& a) {
+  trebi_net* net = B.net;
+  const trebi_net_desc& d = net->desc;
+  int n = d.n_mults;
+  auto S = [](int i) { return std::to_string(i); };
+  if (a.vfinal_L != 1 || a.fc_dim != a.c3)
+    unsupported("ValueFunction(horizon=%d) ends at length %d with fc_dim %d != %d: the reference's own head "
+                "Linear does not fit this shape (temporal.py:190-205)", d.horizon, a.vfinal_L, a.fc_dim, a.c3);
+  struct Stage {
+    Builder::RBRec rb[2];
+    int nrb;
+    std::string down;
+    int C, L;
+    BufRef in, rb0_out, rb_out, down_out;
+  };
+  std::vector<Stage> st;
+  BufRef cur{EXT_X, 0, 0};
+  auto stage = [&](const std::string& p0, const std::string* p1, const std::string& down, int cin, int cout, int L) {
+    Stage s;
+    s.nrb = p1 ? 2 : 1;
+    s.C = cout;
+    s.L = L;
+    s.in = cur;
+    s.down = down;
+    int r0 = net->new_buf((size_t)L * cout);
+    s.rb0_out = {r0, cout, 0};
+    s.rb[0] = B.res_block(p0, cur, cin, cout, L, s.rb0_out, true);
+    s.rb_out = s.rb0_out;
+    if (p1) {
+      int r1 = net->new_buf((size_t)L * cout);
+      s.rb_out = {r1, cout, 0};
+      s.rb[1] = B.res_block(*p1, s.rb0_out, cout, cout, L, s.rb_out, true);
+    }
+    Op dn = B.conv_fwd(down + ".conv", cout, cout, 3, 2, 1, L, nullptr, 0);
+    dn.src = s.rb_out;
+    int db = net->new_buf((size_t)dn.Lout * cout);
+    dn.dst = s.down_out = {db, cout, 0};
+    net->fwd.push_back(dn);
+    cur = s.down_out;
+    st.push_back(s);
+  };
+  for (int i = 0; i < n; ++i) {
+    std::string p0 = "blocks." + S(i) + ".0", p1 = "blocks." + S(i) + ".1";
+    stage(p0, &p1, "blocks." + S(i) + ".2", a.blocks[i].cin, a.blocks[i].cout, a.blocks[i].L);
+  }
+  stage("mid_block1", nullptr, "mid_down1", a.mid1.cin, a.mid1.cout, a.mid1.L);
+  stage("mid_block2", nullptr, "mid_down2", a.mid2.cin, a.mid2.cout, a.mid2.L);
+
+  // head (temporal.py:207-211, 237-238)
+  int fc = a.fc_dim, hd = fc / 2, dim = d.dim;
+  net->fc = fc;
+  net->hd = hd;
+  const float* w1 = B.host("final_block.0.weight", (int64_t)hd * (fc + dim));
+  std::vector<float> w1a((size_t)hd * fc);
+  for (int j = 0; j < hd; ++j)
+    for (int i = 0; i < fc; ++i) w1a[(size_t)j * fc + i] = w1[(size_t)j * (fc + dim) + i];
+  net->head_w1 = B.upload(w1a);
+  net->head_tb = B.time_table("final_block.0.weight", "final_block.0.bias", hd, fc + dim, fc, false);
+  net->head_w2 = B.upload(B.host("final_block.2.weight", hd), hd);
+  net->head_b2 = B.host("final_block.2.bias", 1)[0];
+  Op head;
+  head.kind = 1;
+  head.name = "final_block";
+  head.v_buf = cur.id;
+  head.dv_buf = net->new_buf(fc);
+  head.flops = 2.0 * hd * fc + 2.0 * hd;
+  net->fwd.push_back(head);
+
+  // backward chain
+  BufRef g{head.dv_buf, fc, 0};
+  for (int si = (int)st.size() - 1; si >= 0; --si) {
+    Stage& s = st[si];
+    Op dd = B.down_dgrad(s.down + ".conv", s.C, s.L);
+    dd.src = g;
+    int gb = net->new_buf((size_t)s.L * s.C);
+    dd.dst = {gb, s.C, 0};
+    net->bwd.push_back(dd);
+    g = {gb, s.C, 0};
+    for (int r = s.nrb - 1; r >= 0; --r) {
+      const auto& rec = s.rb[r];
+      BufRef dst;
+      if (si == 0 && r == 0) dst = {EXT_GRAD, 0, 0};
+      else dst = {net->new_buf((size_t)rec.L * rec.cin), rec.cin, 0};
+      B.res_block_bwd(rec, g, dst);
+      g = dst;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// tile selection + op resolution
+// ------------------------------------------------------------------------------------
+int gcd(int a, int b) { return b ? gcd(b, a % b) : a; }
+
+Tile choose_tile(const Op& op, int B) {
+  Tile t;
+  int Lout = op.Lout;
+  if (Lout > 128) unsupported("sequence length %d > 128 is not tiled", Lout);
+  int S = Lout >= 16 ? 1 : 16 / Lout;
+  auto mi_for = [&](int s) {
+    int rows = s * Lout, m = (rows + 15) / 16;
+    return m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : 8;
+  };
+  int units = op.Npad / 16;
+  int tnu = 1;                                      // tile width in 16-column units
+  if (op.gn) {
+    int l = op.gnw.gch / gcd(op.gnw.gch, 16) * 16;  // lcm(gch, 16)
+    tnu = l / 16;
+    if (op.N % GN_GROUPS || op.Npad != op.N || units % tnu)
+      unsupported("GroupNorm(8) over %d channels does not tile", op.N);
+  }
+  if (op.osplit && op.osplit % (16 * tnu)) unsupported("phase split %d not a multiple of the tile", op.osplit);
+  int NI = 1, NG = tnu;
+  if (NG > 8) {
+    if (NG % 2 || NG / 2 > 8) unsupported("column tile of %d is too wide", 16 * tnu);
+    NI = 2;
+    NG /= 2;
+  }
+  int KK = (op.ntaps * op.Cin_p + op.Cin2_p) / 16;
+  // large batches: more candidates per workgroup (weights are reused across more rows) and two
+  // column sub-tiles per wave, as long as the grid still covers the chip several times over
+  long wgs = (long)((B + S - 1) / S) * (units / tnu);
+  auto lds_of = [&](int s, int ni, int ng, int ks) {
+    ConvP p{};
+    p.Lout = op.Lout; p.stride = op.stride; p.ntaps = op.ntaps; p.Cin_p = op.Cin_p;
+    p.x2 = op.src2.id != NONE ? (const float*)1 : nullptr;
+    p.Cin2_p = op.Cin2_p; p.gn = op.gn; p.gch = op.gn ? op.gnw.gch : 1;
+    Tile tt{mi_for(s), ni, ng, ks, s};
+    return conv_lds_bytes(p, tt);
+  };
+  while (wgs >= 2048 && mi_for(S * 2) <= 4 && S * 2 * Lout <= 64 && lds_of(S * 2, NI, NG, 1) <= 96 * 1024) {
+    S *= 2;
+    wgs /= 2;
+  }
+  if (wgs >= 2048 && NI == 1 && (units / tnu) % 2 == 0 && mi_for(S) <= 4 &&
+      !(op.osplit && op.osplit % (32 * tnu))) {
+    NI = 2;                                         // 2*tnu units still hold whole GroupNorm groups
+    wgs /= 2;
+  }
+  int MI = mi_for(S);
+  int KS = std::min(8 / NG, std::max(1, KK / 4));
+  if (KS < 1) KS = 1;
+  t = {MI, NI, NG, KS, S};
+  if (lds_of(S, NI, NG, KS) > 160 * 1024) unsupported("layer %s needs more than 160 KiB of LDS", op.name.c_str());
+  return t;
+}
+
+struct Resolver {
+  const trebi_net* net;
+  std::vector<size_t> off;
+  Binding b;
+  int B;
+  const float* ptr(const BufRef& r, int* ld) const {
+    if (r.id == NONE) { *ld = 0; return nullptr; }
+    if (r.id == EXT_X) { *ld = b.ldx; return b.x; }
+    if (r.id == EXT_OUT) { *ld = b.ldo; return b.out; }
+    if (r.id == EXT_GRAD) { *ld = b.ldg; return b.grad; }
+    *ld = r.ld;
+    return b.ws + off[r.id] + r.coloff;
+  }
+  float* buf(int id) const { return id == NONE ? nullptr : b.ws + off[id]; }
+  ConvP conv(const Op& op) const {
+    ConvP p{};
+    p.x = ptr(op.src, &p.ldx);
+    p.Cin = op.Cin; p.Cin_p = op.Cin_p;
+    p.Lin = op.Lin; p.Lout = op.Lout; p.stride = op.stride; p.pad = op.pad;
+    p.tap_lo = op.tap_lo; p.ntaps = op.ntaps;
+    p.x2 = ptr(op.src2, &p.ldx2);
+    p.Cin2 = op.Cin2; p.Cin2_p = op.Cin2_p;
+    p.w = op.w; p.bias = op.bias; p.bias2 = op.bias2;
+    p.N = op.N; p.Npad = op.Npad;
+    p.out = const_cast<float*>(ptr(op.dst, &p.ldo));
+    p.osplit = op.osplit;
+    p.gn = op.gn ? 1 : 0; p.gch = op.gn ? op.gnw.gch : 1;
+    p.gamma = op.gnw.gamma; p.beta = op.gnw.beta;
+    p.save_y = buf(op.save_y); p.save_stats = buf(op.save_st);
+    p.tbias = op.tbias; p.t = b.t; p.T = net->T;
+    p.res = ptr(op.res, &p.ldres);
+    p.pro = op.pro ? 1 : 0; p.pro_gch = op.pro ? op.pro_gn.gch : 1;
+    p.pro_y = buf(op.pro_y); p.pro_stats = buf(op.pro_st);
+    p.pro_gamma = op.pro_gn.gamma; p.pro_beta = op.pro_gn.beta;
+    p.B = B;
+    return p;
+  }
+  HeadP head(const Op& op, bool want_grad) const {
+    HeadP h{};
+    h.v = buf(op.v_buf);
+    h.w1 = net->head_w1; h.tb = net->head_tb; h.w2 = net->head_w2; h.b2 = net->head_b2;
+    h.t = b.t; h.T = net->T; h.fc = net->fc; h.hd = net->hd; h.B = B;
+    h.y = b.y;
+    h.dv = want_grad ? buf(op.dv_buf) : nullptr;
+    return h;
+  }
+};
+
+// Profiling hook: when set, each GEMM launch is bracketed by HIP events on the launch stream.
+struct GemmProfile {
+  bool enabled = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<double> flops;
+  size_t used = 0;
+  void reset() { used = 0; flops.clear(); }
+  ~GemmProfile() {
+    for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
+};
+
+// Run a list of ops for one net, or for two structurally identical nets in the same launches.
+int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, const trebi_net* n1,
+            const Binding* b1, const std::vector<Op>* ops1, int B, bool want_grad, hipStream_t st,
+            GemmProfile* prof) {
+  Resolver r0{n0, n0->offsets(B), b0, B};
+  Resolver r1{n1 ? n1 : n0, n1 ? n1->offsets(B) : std::vector<size_t>(), n1 ? *b1 : b0, B};
+  int nz = n1 ? 2 : 1;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const Op& op = ops[i];
+    if (op.kind == 1) {
+      HeadLaunch L{};
+      L.p[0] = r0.head(op, want_grad);
+      if (n1) L.p[1] = r1.head((*ops1)[i], want_grad);
+      HIPCHK(launch_head(L, nz, st));
+      continue;
+    }
+    ConvLaunch L{};
+    L.p[0] = r0.conv(op);
+    if (n1) L.p[1] = r1.conv((*ops1)[i]);
+    Tile tl;
+    try {
+      tl = choose_tile(op, B);
+    } catch (const Unsupported& u) {
+      return fail(TREBI_UNSUPPORTED_CONFIG, "%s", u.msg.c_str());
+    }
+    // shapes the kernel and its grid assume, checked on the host before every launch
+    if (tl.S * op.Lout > 16 * tl.MI || op.Npad % (16 * tl.NI * tl.NG) || 64 * tl.NG * tl.KS > 512 ||
+        (op.pro && (op.stride != 1 || op.Lin != op.Lout)) || !L.p[0].x || !L.p[0].out)
+      return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
+    if (prof && prof->enabled) {
+      if (prof->used == prof->ev.size()) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        prof->ev.push_back({a, b});
+      }
+      HIPCHK(hipEventRecord(prof->ev[prof->used].first, st));
+      HIPCHK(launch_conv(L, nz, tl, st));
+      HIPCHK(hipEventRecord(prof->ev[prof->used].second, st));
+      prof->flops.push_back(op.flops * B * nz);
+      prof->used++;
+    } else {
+      HIPCHK(launch_conv(L, nz, tl, st));
+    }
+  }
+  return 0;
+}
+
+bool same_arch(const trebi_net* a, const trebi_net* b) {
+  const trebi_net_desc &x = a->desc, &y = b->desc;
+  if (x.kind != y.kind || x.horizon != y.horizon || x.transition_dim != y.transition_dim || x.dim != y.dim ||
+      x.n_mults != y.n_mults || a->T != b->T)
+    return false;
+  for (int i = 0; i < x.n_mults; ++i)
+    if (x.dim_mults[i] != y.dim_mults[i]) return false;
+  return a->fwd.size() == b->fwd.size() && a->bwd.size() == b->bwd.size();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// extern "C": basics
+// ------------------------------------------------------------------------------------
+extern "C" const char* trebi_last_error(void) { return g_err.c_str(); }
+extern "C" int trebi_version(void) { return 1; }
+
+extern "C" int trebi_ctx_create(int device, trebi_ctx** out) {
+  if (!out) return fail(TREBI_BAD_ARG, "out is null");
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(TREBI_BAD_ARG, "device %d out of range (%d visible)", device, n);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(TREBI_UNSUPPORTED_CONFIG, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                prop.gcnArchName);
+  HIPCHK(conv_init_device());
+  *out = new trebi_ctx{device};
+  return 0;
+}
+extern "C" void trebi_ctx_destroy(trebi_ctx* ctx) { delete ctx; }
+
+extern "C" int trebi_net_param_count(const trebi_net_desc* desc) {
+  if (int e = check_desc(desc)) return e;
+  return (int)param_specs(*desc).size();
+}
+extern "C" int trebi_net_param_info(const trebi_net_desc* desc, int i, char* name_out, size_t name_cap,
+                                    int64_t* numel_out) {
+  if (int e = check_desc(desc)) return e;
+  auto s = param_specs(*desc);
+  if (i < 0 || i >= (int)s.size()) return fail(TREBI_BAD_ARG, "parameter index %d out of range", i);
+  if (name_out && name_cap) {
+    strncpy(name_out, s[i].name.c_str(), name_cap - 1);
+    name_out[name_cap - 1] = 0;
+  }
+  if (numel_out) *numel_out = s[i].numel;
+  return 0;
+}
+
+extern "C" int trebi_net_create(trebi_ctx* ctx, const trebi_net_desc* desc, const char* const* names,
+                                const float* const* tensors, const int64_t* numels, int n_tensors,
+                                trebi_net** out) {
+  if (!ctx || !out || !names || !tensors || !numels) return fail(TREBI_BAD_ARG, "null argument");
+  if (int e = check_desc(desc)) return e;
+  HIPCHK(hipSetDevice(ctx->device));
+  auto specs = param_specs(*desc);
+  std::unique_ptr<trebi_net> net(new trebi_net);
+  net->ctx = ctx;
+  net->desc = *desc;
+  net->T = desc->max_timesteps;
+  Builder B;
+  B.net = net.get();
+  B.dim = desc->dim;
+  B.T = net->T;
+  for (int i = 0; i < n_tensors; ++i) {
+    if (!names[i] || !tensors[i]) return fail(TREBI_BAD_ARG, "tensor table entry %d is null", i);
+    B.sd[names[i]] = {tensors[i], numels[i]};
+  }
+  for (auto& s : specs) {
+    auto it = B.sd.find(s.name);
+    if (it == B.sd.end()) return fail(TREBI_BAD_SHAPE, "state_dict is missing '%s'", s.name.c_str());
+    if (it->second.second != s.numel)
+      return fail(TREBI_BAD_SHAPE, "'%s' has %lld elements, the architecture needs %lld", s.name.c_str(),
+                  (long long)it->second.second, (long long)s.numel);
+  }
+  if ((size_t)n_tensors != specs.size())
+    return fail(TREBI_BAD_SHAPE, "state_dict has %d tensors, the architecture has %zu", n_tensors, specs.size());
+  try {
+    int dim = desc->dim;
+    const float* w1 = B.upload(B.host("time_mlp.1.weight", (int64_t)4 * dim * dim), (size_t)4 * dim * dim);
+    const float* b1 = B.upload(B.host("time_mlp.1.bias", 4 * dim), 4 * dim);
+    const float* w2 = B.upload(B.host("time_mlp.3.weight", (int64_t)4 * dim * dim), (size_t)4 * dim * dim);
+    const float* b2 = B.upload(B.host("time_mlp.3.bias", dim), dim);
+    float* temb = B.dalloc((size_t)net->T * dim);
+    HIPCHK(launch_time_embed(w1, b1, w2, b2, dim, net->T, temb, 0));
+    B.temb = temb;
+    ArchPlan a = make_arch(*desc);
+    if (desc->kind == 0) build_unet(B, a); else build_value(B, a);
+    // every layer must tile for at least a batch of one
+    for (auto* ops : {&net->fwd, &net->bwd})
+      for (auto& op : *ops)
+        if (op.kind == 0) (void)choose_tile(op, 1);
+  } catch (const Unsupported& u) {
+    return fail(TREBI_UNSUPPORTED_CONFIG, "%s", u.msg.c_str());
+  } catch (const BadShape& b) {
+    return fail(TREBI_BAD_SHAPE, "%s", b.msg.c_str());
+  }
+  for (auto& op : net->fwd) net->flops_fwd += op.flops;
+  for (auto& op : net->bwd) net->flops_bwd += op.flops;
+  HIPCHK(hipDeviceSynchronize());
+  *out = net.release();
+  return 0;
+}
+extern "C" void trebi_net_destroy(trebi_net* net) { delete net; }
+
+extern "C" size_t trebi_unet_workspace_bytes(const trebi_net* net, int B) {
+  return net && B > 0 ? net->ws_floats(B) * sizeof(float) : 0;
+}
+extern "C" size_t trebi_value_workspace_bytes(const trebi_net* net, int B) {
+  return net && B > 0 ? net->ws_floats(B) * sizeof(float) : 0;
+}
+
+extern "C" int trebi_unet_forward(trebi_net* net, const float* x, int ldx, const int64_t* t, float* out, int ldo,
+                                  int B, void* ws, size_t ws_bytes, void* stream) {
+  if (!net || !x || !t || !out || !ws) return fail(TREBI_BAD_ARG, "null argument");
+  if (net->desc.kind != 0) return fail(TREBI_BAD_ARG, "not a TemporalUnet");
+  if (B < 1 || ldx < net->desc.transition_dim || ldo < net->desc.transition_dim)
+    return fail(TREBI_BAD_SHAPE, "B=%d ldx=%d ldo=%d do not fit transition_dim=%d", B, ldx, ldo,
+                net->desc.transition_dim);
+  if (ws_bytes < trebi_unet_workspace_bytes(net, B))
+    return fail(TREBI_WORKSPACE_TOO_SMALL, "workspace %zu < %zu bytes", ws_bytes, trebi_unet_workspace_bytes(net, B));
+  Binding b;
+  b.x = x; b.ldx = ldx; b.out = out; b.ldo = ldo; b.t = (const long long*)t; b.ws = (float*)ws;
+  return run_ops(net->fwd, net, b, nullptr, nullptr, nullptr, B, false, (hipStream_t)stream, nullptr);
+}
+
+static int value_run(trebi_net* n0, const Binding& b0, trebi_net* n1, const Binding* b1, int B, bool grad,
+                     hipStream_t st, GemmProfile* prof) {
+  if (int e = run_ops(n0->fwd, n0, b0, n1, b1, n1 ? &n1->fwd : nullptr, B, grad, st, prof)) return e;
+  if (grad)
+    if (int e = run_ops(n0->bwd, n0, b0, n1, b1, n1 ? &n1->bwd : nullptr, B, true, st, prof)) return e;
+  return 0;
+}
+
+extern "C" int trebi_value_gradients(trebi_net* net, const float* x, int ldx, const int64_t* t, float* y,
+                                     float* grad, int ldg, int B, void* ws, size_t ws_bytes, void* stream) {
+  if (!net || !x || !t || !y || !ws) return fail(TREBI_BAD_ARG, "null argument");
+  if (net->desc.kind != 1) return fail(TREBI_BAD_ARG, "not a ValueFunction");
+  int D = net->desc.transition_dim;
+  if (B < 1 || ldx < D || (grad && ldg < D))
+    return fail(TREBI_BAD_SHAPE, "B=%d ldx=%d ldg=%d do not fit transition_dim=%d", B, ldx, ldg, D);
+  if (ws_bytes < trebi_value_workspace_bytes(net, B))
+    return fail(TREBI_WORKSPACE_TOO_SMALL, "workspace %zu < %zu bytes", ws_bytes,
+                trebi_value_workspace_bytes(net, B));
+  hipStream_t st = (hipStream_t)stream;
+  if (grad && ldg > D) HIPCHK(hipMemsetAsync(grad, 0, (size_t)B * net->desc.horizon * ldg * sizeof(float), st));
+  Binding b;
+  b.x = x; b.ldx = ldx; b.grad = grad; b.ldg = ldg; b.t = (const long long*)t; b.ws = (float*)ws; b.y = y;
+  return value_run(net, b, nullptr, nullptr, B, grad != nullptr, st, nullptr);
+}
+
+// ------------------------------------------------------------------------------------
+// elementwise steps + selection
+// ------------------------------------------------------------------------------------
+static int make_step(const trebi_step_desc* d, const float* const* cond, StepP* s) {
+  if (!d) return fail(TREBI_BAD_ARG, "null step descriptor");
+  if (d->n_cond < 0 || d->n_cond > 4) return fail(TREBI_UNSUPPORTED_CONFIG, "at most 4 conditioned timesteps");
+  if (d->transition_dim < d->action_dim + d->observation_dim || d->horizon < 1 || d->n_timesteps < 1)
+    return fail(TREBI_BAD_SHAPE, "inconsistent step descriptor");
+  s->H = d->horizon; s->D = d->transition_dim; s->act = d->action_dim; s->obs = d->observation_dim;
+  s->T = d->n_timesteps; s->scale = d->scale; s->t_stopgrad = d->t_stopgrad;
+  s->scale_by_std = d->scale_grad_by_std; s->state_mask = d->state_grad_mask; s->cgw = d->cost_grad_weight;
+  s->guide_type = d->guide_type; s->n_cond = d->n_cond;
+  for (int k = 0; k < d->n_cond; ++k) {
+    if (!cond || !cond[k]) return fail(TREBI_BAD_ARG, "cond[%d] is null", k);
+    if (d->cond_index[k] < 0 || d->cond_index[k] >= d->horizon)
+      return fail(TREBI_BAD_SHAPE, "conditioned index %d outside the horizon", d->cond_index[k]);
+    s->cond_index[k] = d->cond_index[k];
+    s->cond[k] = cond[k];
+  }
+  return 0;
+}
+
+extern "C" int trebi_guide_update(trebi_ctx* ctx, const trebi_step_desc* d, float* x, const float* r_grad,
+                                  const float* cost_grad, const float* cost_y, const float* thr, const int64_t* t,
+                                  const float* plv, const float* const* cond, int B, void* stream) {
+  if (!ctx || !x || !r_grad || !t || !plv || B < 1) return fail(TREBI_BAD_ARG, "null argument");
+  if (cost_grad && (!cost_y || !thr)) return fail(TREBI_BAD_ARG, "cost_grad needs cost_y and cost_threshold");
+  if (d && d->guide_type != 0 && d->guide_type != 1) return fail(TREBI_BAD_ARG, "guide_type must be 0 or 1");
+  StepP s{};
+  if (int e = make_step(d, cond, &s)) return e;
+  HIPCHK(launch_guide_update(s, x, r_grad, cost_grad, cost_y, thr, (const long long*)t, plv, B, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int trebi_ddpm_update(trebi_ctx* ctx, const trebi_step_desc* d, float* x, const float* x0,
+                                 const float* noise, const int64_t* t, const float* plv, const float* c1,
+                                 const float* c2, const float* const* cond, int B, void* stream) {
+  if (!ctx || !x || !x0 || !noise || !t || !plv || !c1 || !c2 || B < 1) return fail(TREBI_BAD_ARG, "null argument");
+  StepP s{};
+  if (int e = make_step(d, cond, &s)) return e;
+  HIPCHK(launch_ddpm_update(s, x, x0, noise, (const long long*)t, plv, c1, c2, B, nullptr, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int trebi_feasibility_rule(trebi_ctx* ctx, const float* r_y, const float* cost_y, const float* thr,
+                                      int n, float* out, void* stream) {
+  if (!ctx || !r_y || !cost_y || !thr || !out || n < 1) return fail(TREBI_BAD_ARG, "null argument");
+  HIPCHK(launch_feasibility(r_y, cost_y, thr, n, out, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int trebi_argsort_desc(trebi_ctx* ctx, const float* values, int n, int64_t* order, void* stream) {
+  if (!ctx || !values || !order || n < 1) return fail(TREBI_BAD_ARG, "null argument");
+  HIPCHK(launch_argsort_desc(values, n, (long long*)order, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int trebi_group_argmax(trebi_ctx* ctx, const float* values, int n_groups, int per, int64_t* best,
+                                  void* stream) {
+  if (!ctx || !values || !best || n_groups < 1 || per < 1) return fail(TREBI_BAD_ARG, "null argument");
+  HIPCHK(launch_group_argmax(values, n_groups, per, (long long*)best, (hipStream_t)stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// the captured sampling loop
+// ------------------------------------------------------------------------------------
+struct trebi_sampler {
+  trebi_ctx* ctx = nullptr;
+  trebi_net *unet = nullptr, *reward = nullptr, *cost = nullptr;
+  trebi_sampler_desc d{};
+  int B = 0;
+  bool dual = false;
+  void* arena = nullptr;            // one device allocation: tables + workspaces + state
+  float *plv = nullptr, *c1 = nullptr, *c2 = nullptr;
+  long long* tbuf = nullptr;        // [T, B] one timestep vector per step
+  float *ws_u = nullptr, *ws_r = nullptr, *ws_c = nullptr;
+  float *x0 = nullptr, *rgrad = nullptr, *cgrad = nullptr;
+  // graph cache, keyed by the pointers baked into it
+  hipGraphExec_t exec = nullptr;
+  const void* key[12] = {};
+  GemmProfile prof;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  bool have_loop_time = false;
+  ~trebi_sampler() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (arena) (void)hipFree(arena);
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
+  }
+};
+
+extern "C" int trebi_sampler_create(trebi_ctx* ctx, trebi_net* unet, trebi_net* reward, trebi_net* cost,
+                                    const trebi_sampler_desc* desc, const float* plv, const float* c1,
+                                    const float* c2, int B, trebi_sampler** out) {
+  if (!ctx || !unet || !desc || !plv || !c1 || !c2 || !out || B < 1) return fail(TREBI_BAD_ARG, "null argument");
+  const trebi_step_desc& sd = desc->step;
+  if (desc->kind < 0 || desc->kind > 2) return fail(TREBI_BAD_ARG, "sampler kind must be 0, 1 or 2");
+  if (desc->kind >= 1 && !reward) return fail(TREBI_BAD_ARG, "guided sampling needs a reward ValueFunction");
+  if (desc->kind == 2 && !cost) return fail(TREBI_BAD_ARG, "constrained sampling needs a cost ValueFunction");
+  if (desc->kind >= 1 && desc->n_guide_steps < 1)
+    return fail(TREBI_UNSUPPORTED_CONFIG, "n_guide_steps must be >= 1 (the reference leaves y undefined at 0)");
+  if (desc->kind == 2 && sd.guide_type != 0 && sd.guide_type != 1) return fail(TREBI_BAD_ARG, "guide_type must be 0 or 1");
+  if (unet->desc.kind != 0 || (reward && reward->desc.kind != 1) || (cost && cost->desc.kind != 1))
+    return fail(TREBI_BAD_ARG, "network kinds do not match their roles");
+  int D = sd.transition_dim, H = sd.horizon, T = sd.n_timesteps;
+  if (unet->desc.transition_dim != D || unet->desc.horizon != H)
+    return fail(TREBI_BAD_SHAPE, "TemporalUnet is [%d,%d], the sampler wants [%d,%d]", unet->desc.horizon,
+                unet->desc.transition_dim, H, D);
+  for (trebi_net* v : {reward, cost})
+    if (v && (v->desc.transition_dim > D || v->desc.horizon != H))
+      return fail(TREBI_BAD_SHAPE, "ValueFunction shape does not fit the trajectories");
+  for (trebi_net* v : {unet, reward, cost})
+    if (v && v->T < T) return fail(TREBI_BAD_SHAPE, "network time table (%d) shorter than n_timesteps (%d)", v->T, T);
+  StepP tmp{};
+  const float* dummy[4] = {plv, plv, plv, plv};
+  if (int e = make_step(&sd, dummy, &tmp)) return e;
+  HIPCHK(hipSetDevice(ctx->device));
+  std::unique_ptr<trebi_sampler> s(new trebi_sampler);
+  s->ctx = ctx; s->unet = unet; s->d = *desc; s->B = B;
+  s->reward = desc->kind >= 1 ? reward : nullptr;
+  s->cost = desc->kind == 2 ? cost : nullptr;
+  s->dual = s->reward && s->cost && same_arch(s->reward, s->cost);
+  auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+  size_t per = (size_t)B * H * D;
+  size_t n_tab = al(3 * (size_t)T), n_t = al((size_t)T * B * 2), n_u = al(unet->ws_floats(B)),
+         n_r = s->reward ? al(s->reward->ws_floats(B)) : 0, n_c = s->cost ? al(s->cost->ws_floats(B)) : 0,
+         n_x = al(per);
+  size_t total = n_tab + n_t + n_u + n_r + n_c + 3 * n_x;
+  HIPCHK(hipMalloc(&s->arena, total * sizeof(float)));
+  float* p = (float*)s->arena;
+  s->plv = p; s->c1 = p + T; s->c2 = p + 2 * T; p += n_tab;
+  s->tbuf = (long long*)p; p += n_t;
+  s->ws_u = p; p += n_u;
+  s->ws_r = p; p += n_r;
+  s->ws_c = p; p += n_c;
+  s->x0 = p; p += n_x;
+  s->rgrad = p; p += n_x;
+  s->cgrad = p; p += n_x;
+  HIPCHK(hipMemcpy(s->plv, plv, T * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->c1, c1, T * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->c2, c2, T * sizeof(float), hipMemcpyHostToDevice));
+  for (int i = 0; i < T; ++i) HIPCHK(launch_fill_t(s->tbuf + (size_t)i * B, B, i, 0));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipEventCreate(&s->ev_a));
+  HIPCHK(hipEventCreate(&s->ev_b));
+  *out = s.release();
+  return 0;
+}
+extern "C" void trebi_sampler_destroy(trebi_sampler* s) { delete s; }
+
+// Enqueue the whole loop on `st` (diffusion.py:192-204 with the chosen sample function inlined).
+static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const* cond, const float* thr,
+                        float* x, float* values, float* costs, float* chain, hipStream_t st, GemmProfile* prof) {
+  const trebi_sampler_desc& d = s->d;
+  const int B = s->B, T = d.step.n_timesteps, H = d.step.horizon, D = d.step.transition_dim;
+  const size_t per = (size_t)B * H * D;
+  StepP sp{};
+  if (int e = make_step(&d.step, cond, &sp)) return e;
+  HIPCHK(launch_init_x(sp, x, noise, B, chain, st));
+  if (d.kind == 0 || d.kind == 1) HIPCHK(hipMemsetAsync(costs, 0, B * sizeof(float), st));
+  if (d.kind == 0) HIPCHK(hipMemsetAsync(values, 0, B * sizeof(float), st));
+  const int Dv = s->reward ? s->reward->desc.transition_dim : D;
+  if (s->reward && Dv < D) {      // guides.py:13 reads a column slice; the other columns get zero gradient
+    HIPCHK(hipMemsetAsync(s->rgrad, 0, per * sizeof(float), st));
+    if (s->cost) HIPCHK(hipMemsetAsync(s->cgrad, 0, per * sizeof(float), st));
+  }
+  for (int i = T - 1; i >= 0; --i) {
+    const long long* t = s->tbuf + (size_t)i * B;
+    if (d.kind >= 1) {
+      const bool stopped = i < d.step.t_stopgrad;          // gradient is zeroed: x cannot change (functions.py:116)
+      const bool dead = stopped && i != 0;                 // ... and y is only returned from the last step
+      if (!(dead && d.skip_dead_evals)) {
+        for (int k = 0; k < d.n_guide_steps; ++k) {
+          Binding br, bc;
+          br.x = x; br.ldx = D; br.grad = s->rgrad; br.ldg = D; br.t = t; br.ws = s->ws_r; br.y = values;
+          bc = br; bc.grad = s->cgrad; bc.ws = s->ws_c; bc.y = costs;
+          const bool grad = !stopped;
+          if (s->cost && s->dual) {
+            if (int e = value_run(s->cost, bc, s->reward, &br, B, grad, st, prof)) return e;
+          } else {
+            if (s->cost) if (int e = value_run(s->cost, bc, nullptr, nullptr, B, grad, st, prof)) return e;
+            if (int e = value_run(s->reward, br, nullptr, nullptr, B, grad, st, prof)) return e;
+          }
+          if (grad)
+            HIPCHK(launch_guide_update(sp, x, s->rgrad, s->cost ? s->cgrad : nullptr, costs, thr, t, s->plv, B, st));
+          else if (d.skip_dead_evals)
+            break;                                         // same x => same y on every further iteration
+        }
+      }
+    }
+    Binding bu;
+    bu.x = x; bu.ldx = D; bu.out = s->x0; bu.ldo = D; bu.t = t; bu.ws = s->ws_u;
+    if (int e = run_ops(s->unet->fwd, s->unet, bu, nullptr, nullptr, nullptr, B, false, st, prof)) return e;
+    float* ch = chain ? chain + (size_t)(T - i) * per : nullptr;
+    HIPCHK(launch_ddpm_update(sp, x, s->x0, noise + (size_t)(T - i) * per, t, s->plv, s->c1, s->c2, B, ch, st));
+  }
+  return 0;
+}
+
+extern "C" int trebi_sampler_run(trebi_sampler* s, const float* noise, const float* const* cond, const float* thr,
+                                 float* x, float* values, float* costs, float* chain, void* stream) {
+  if (!s || !noise || !x || !values || !costs) return fail(TREBI_BAD_ARG, "null argument");
+  if (s->d.kind == 2 && !thr) return fail(TREBI_BAD_ARG, "constrained sampling needs cost_threshold");
+  if (s->d.step.n_cond > 0 && !cond) return fail(TREBI_BAD_ARG, "cond is null");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(s->ctx->device));
+  if (s->prof.enabled) {          // profiled run: plain launches bracketed by events
+    s->prof.reset();
+    HIPCHK(hipEventRecord(s->ev_a, st));
+    if (int e = enqueue_loop(s, noise, cond, thr, x, values, costs, chain, st, &s->prof)) return e;
+    HIPCHK(hipEventRecord(s->ev_b, st));
+    s->have_loop_time = true;
+    return 0;
+  }
+  if (!s->d.use_graph) return enqueue_loop(s, noise, cond, thr, x, values, costs, chain, st, nullptr);
+  const void* key[12] = {noise, thr, x, values, costs, chain, st};
+  for (int k = 0; k < s->d.step.n_cond; ++k) key[7 + k] = cond[k];
+  if (!s->exec || memcmp(key, s->key, sizeof key) != 0) {
+    if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+    hipStream_t cap;
+    HIPCHK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    hipError_t e0 = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+    int rc = 0;
+    if (e0 == hipSuccess) rc = enqueue_loop(s, noise, cond, thr, x, values, costs, chain, cap, nullptr);
+    hipError_t e1 = e0 == hipSuccess ? hipStreamEndCapture(cap, &graph) : e0;
+    (void)hipStreamDestroy(cap);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e1 != hipSuccess) return fail(TREBI_HIP_ERROR, "graph capture failed: %s", hipGetErrorString(e1));
+    hipError_t e2 = hipGraphInstantiate(&s->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) { s->exec = nullptr; return fail(TREBI_HIP_ERROR, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
+    memcpy(s->key, key, sizeof key);
+  }
+  HIPCHK(hipGraphLaunch(s->exec, st));
+  return 0;
+}
+
+extern "C" int trebi_sampler_set_profiling(trebi_sampler* s, int enabled) {
+  if (!s) return fail(TREBI_BAD_ARG, "null sampler");
+  s->prof.enabled = enabled != 0;
+  return 0;
+}
+
+extern "C" int trebi_sampler_get_profile(trebi_sampler* s, double* gemm_us_total, int64_t* gemm_launches,
+                                         double* gemm_flops_total, double* loop_us_total) {
+  if (!s) return fail(TREBI_BAD_ARG, "null sampler");
+  if (!s->have_loop_time) return fail(TREBI_BAD_ARG, "no profiled run recorded");
+  HIPCHK(hipEventSynchronize(s->ev_b));
+  double us = 0, fl = 0;
+  for (size_t i = 0; i < s->prof.used; ++i) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->prof.ev[i].first, s->prof.ev[i].second));
+    us += 1e3 * ms;
+    fl += s->prof.flops[i];
+  }
+  float lms = 0;
+  HIPCHK(hipEventElapsedTime(&lms, s->ev_a, s->ev_b));
+  if (gemm_us_total) *gemm_us_total = us;
+  if (gemm_launches) *gemm_launches = (int64_t)s->prof.used;
+  if (gemm_flops_total) *gemm_flops_total = fl;
+  if (loop_us_total) *loop_us_total = 1e3 * lms;
+  return 0;
+}
+
+// FLOP accounting hook used by bench.py / DESIGN.md (algorithmic, zero-padding taps excluded).
+extern "C" double trebi_net_flops(const trebi_net* net, int backward) {
+  return net ? (backward ? net->flops_bwd : net->flops_fwd) : 0.0;
+}
