@@ -1,0 +1,203 @@
+"""bench.py -- cost-guided trajectories/sec of the TREBI planning hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" is one complete planning call of BASELINE.json configs[1]: halfcheetah (obs 17 + act 6),
+H=32, 20 denoise steps, 64 candidates per GPU, reward + cost guide (n_guide_steps=2, scale=0.001,
+t_stopgrad=4, cost_grad_weight=5, guide_type=0; config/locomotion.py:153-203,305-309): noise draw,
+the captured loop (20 x (2 x [cost+reward ValueFunction forward+backward, guide update] + TemporalUnet
+forward + DDPM update)), then the all-gather of (values, costs), feasibility rule and argsort.  Weights
+are seeded random (no pretrained checkpoints offline), data is synthetic.  Candidates are sharded over
+ranks with no collective inside the loop (weak scaling: 64 candidates per GPU).
+
+Prints ONE JSON line on rank 0 (see the "Measurement" section of DESIGN.md for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'safe-offline-rl-with-diffusion-model_amd'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H, T, OBS, ACT, DIM = 32, 20, 17, 6, 32
+MULTS = (1, 2, 4, 8)
+PLAN_KW = dict(scale=0.001, t_stopgrad=4, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0)
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def build_models(device):
+    from trebi_amd import spec, synth
+    from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
+    from diffuser.sampling import ValueGuide
+    D = OBS + ACT
+
+    def mk(cls, shapes, seed):
+        net = cls(H, D, 0, dim=DIM, dim_mults=MULTS)
+        sd = synth.synth_state_dict(shapes, seed)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        return net, sd
+    kw = dict(n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False)
+    unet, sd_u = mk(TemporalUnet, spec.unet_param_shapes(H, D, DIM, MULTS), 100)
+    rnet, sd_r = mk(ValueFunction, spec.value_param_shapes(H, D, DIM, MULTS), 101)
+    cnet, sd_c = mk(ValueFunction, spec.value_param_shapes(H, D, DIM, MULTS), 102)
+    diff = GaussianDiffusion(unet, H, OBS, ACT, **kw).to(device)
+    guide = ValueGuide(ValueDiffusion(rnet, H, OBS, ACT, **kw)).to(device)
+    cguide = ValueGuide(ValueDiffusion(cnet, H, OBS, ACT, **kw)).to(device)
+    return diff, guide, cguide, (sd_u, sd_r, sd_c)
+
+
+def cpu_baseline(sds, B, thr, runs=2):
+    """The numpy oracle (a port of the reference path, oracle/trebi_oracle.py) on this box's host cores:
+    the same workload (B candidates, full 20-step constrained loop), `runs` times."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import trebi_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
+    D = OBS + ACT
+    u = O.TemporalUnet(sds[0], H, D, DIM, MULTS)
+    r = O.ValueFunction(sds[1], H, D, DIM, MULTS)
+    c = O.ValueFunction(sds[2], H, D, DIM, MULTS)
+    diff = O.GaussianDiffusion(u, H, OBS, ACT, T)
+    rng = np.random.default_rng(0)
+    cond = {0: np.repeat(rng.standard_normal((1, OBS)).astype(np.float32), B, 0)}
+    best = None
+    for _ in range(runs):
+        noise = rng.standard_normal((T + 1, B, H, D)).astype(np.float32)
+        t0 = time.perf_counter()
+        diff.p_sample_loop((B, H, D), cond, noise, O.n_step_guided_and_constrained_p_sample,
+                           guide=O.ValueGuide(r), cost_guide=O.ValueGuide(c),
+                           cost_threshold=np.full(B, thr, np.float32), **PLAN_KW)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return dict(value=B / best, unit='trajectories/s', cores=int(cores), kind='port',
+                sample=f'{runs} full planning calls of the same workload ({B} candidates, H={H}, {T} steps, '
+                       f'reward+cost guide) through oracle/trebi_oracle.py (numpy/OpenBLAS), best of {runs}')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='candidates per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--skip-dead-evals', action='store_true',
+                    help='also drop guide evaluations whose result cannot reach an output (not the default)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N with N > 1 must be launched through torch.distributed.run '
+                     '(one process per GPU)')
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X: there is no CPU path')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)
+
+    from diffuser.sampling import n_step_guided_and_constrained_p_sample as fn
+    from trebi_amd.parallel import ShardedPlanner
+    diff, guide, cguide, sds = build_models(device)
+    planner = ShardedPlanner(diff)
+    B = args.batch
+    n_global = B * world
+    obs = torch.from_numpy(np.random.default_rng(1).standard_normal(OBS).astype(np.float32)).to(device)
+    D = OBS + ACT
+
+    # synthetic budget: the median cost at t = T-1 of x_T, so about half the candidates take the
+    # penalised branch (random-init nets give O(0.1) costs, not MuJoCo budgets)
+    x_T = torch.randn(B, H, D, device=device, generator=torch.Generator(device).manual_seed(2))
+    x_T[:, 0, ACT:] = obs
+    c19 = cguide(x_T, None, torch.full((B,), T - 1, device=device, dtype=torch.long))
+    thr = float(c19.median())
+    if world > 1:
+        tt = torch.tensor([thr], device=device)
+        dist.broadcast(tt, 0)
+        thr = float(tt)
+    kw = dict(PLAN_KW, guide=guide, cost_guide=cguide, skip_dead_evals=args.skip_dead_evals)
+
+    def step():
+        return planner.plan(obs, n_global, H, fn, cost_threshold=thr, **kw)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(max(args.warmup, 1)):
+        plan = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        td = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dt = float(td)
+    assert torch.isfinite(plan.best_trajectory).all()
+
+    # ---- roofline of the dominant kernel (the implicit-GEMM conv), measured live with HIP events on
+    # the launch stream: one profiled planning call with plain launches bracketed by events.
+    lo, hi = plan.local_slice
+    diff.sample_raw((hi - lo, H, D), {0: obs[None].expand(hi - lo, -1)}, sample_fn=fn, cost_threshold=thr,
+                    profile=True, **kw)
+    torch.cuda.synchronize(device)
+    prof = diff.last_profile
+
+    if rank == 0:
+        F_unet = diff.model.flops()
+        F_vf = guide._net().flops() + guide._net().flops(backward=True)
+        ngs, ts = PLAN_KW['n_guide_steps'], PLAN_KW['t_stopgrad']
+        gflop_nominal = T * (F_unet + 2 * ngs * F_vf) / 1e9              # SURVEY.md 8d formula
+        avg_us = prof['gemm_us'] / max(prof['gemm_launches'], 1)
+        flops_per_launch = prof['gemm_flops'] / max(prof['gemm_launches'], 1)
+        achieved = flops_per_launch / (avg_us * 1e-6) / 1e12
+        out = {
+            'metric': 'cost-guided trajectories/sec (H=32, 20 denoise steps)',
+            'value': n_global * args.steps / dt,
+            'unit': 'trajectories/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic (seeded random weights, N(0,1) noise and observation)',
+            'config': {'workload': 'halfcheetah-medium-expert-v2 shapes (obs 17 + act 6), H=32, T=20, '
+                                   f'{B} candidates per GPU, reward+cost guide, n_guide_steps=2, '
+                                   'TemporalUnet/ValueFunction dim_mults (1,2,4,8)',
+                       'candidates_per_gpu': B, 'global_candidates': n_global,
+                       'parallelism': f'candidate-sharded x{world}', 'skip_dead_evals': bool(args.skip_dead_evals),
+                       'algorithmic_gflop_per_trajectory': gflop_nominal},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_kernel (implicit-GEMM Conv1d, f32 MFMA)',
+                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'avg_launch_us': avg_us, 'launches_per_step': prof['gemm_launches'],
+                         'algorithmic_flops_per_launch': flops_per_launch,
+                         'eager_loop_ms': prof['loop_us'] / 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(sds, B, thr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -53,24 +53,22 @@ def linear(x, w, b):
     return (x @ w.T + b).astype(F32)
 
 
-def _im2col(x, k, stride, pad):
-    """x [B,C,L] -> cols [B, Lout, C*k] with column index c*k + tap (matches w.reshape(Co, C*k))."""
-    B, C, L = x.shape
-    xp = np.zeros((B, C, L + 2 * pad), F32)
-    xp[:, :, pad:pad + L] = x
-    Lout = (L + 2 * pad - k) // stride + 1
-    idx = (np.arange(Lout) * stride)[:, None] + np.arange(k)[None, :]      # [Lout, k]
-    cols = xp[:, :, idx]                                                    # [B, C, Lout, k]
-    return cols.transpose(0, 2, 1, 3).reshape(B, Lout, C * k), Lout
-
-
 def conv1d(x, w, b, stride=1, pad=0):
-    """torch.nn.Conv1d forward.  x [B,Ci,L], w [Co,Ci,k], b [Co] -> [B,Co,Lout]."""
+    """torch.nn.Conv1d forward.  x [B,Ci,L], w [Co,Ci,k], b [Co] -> [B,Co,Lout].
+    y[b,:,lo] = sum_tap w[:,:,tap] @ xpad[b,:,lo*stride+tap]  -- one sgemm per tap."""
     Co, Ci, k = w.shape
-    cols, Lout = _im2col(x, k, stride, pad)
-    y = cols @ w.reshape(Co, Ci * k).T
+    B, _, L = x.shape
+    Lout = (L + 2 * pad - k) // stride + 1
+    xp = np.zeros((B, L + 2 * pad, Ci), F32)                # channels-last copy so each tap is a GEMM
+    xp[:, pad:pad + L, :] = x.transpose(0, 2, 1)
+    y = np.zeros((B * Lout, Co), F32)
+    wt = np.ascontiguousarray(w.transpose(2, 1, 0))          # [k, Ci, Co], contiguous so BLAS is used
+    for tap in range(k):
+        rows = np.ascontiguousarray(xp[:, tap:tap + (Lout - 1) * stride + 1:stride, :]).reshape(B * Lout, Ci)
+        y += rows @ wt[tap]
+    y = y.reshape(B, Lout, Co)
     if b is not None:
-        y = y + b
+        y += b
     return np.ascontiguousarray(y.transpose(0, 2, 1), dtype=F32)
 
 
@@ -78,12 +76,12 @@ def conv1d_input_grad(dy, w, L_in, stride=1, pad=0):
     """d(sum)/dx of conv1d: scatter-add of dy[b,:,lo] @ w[:,:,tap] to x position lo*stride+tap-pad."""
     Co, Ci, k = w.shape
     B, _, Lout = dy.shape
-    dxp = np.zeros((B, Ci, L_in + 2 * pad + stride), F32)
-    for tap in range(k):
-        contrib = np.einsum('bol,oi->bil', dy, w[:, :, tap]).astype(F32)    # [B,Ci,Lout]
-        pos = np.arange(Lout) * stride + tap
-        np.add.at(dxp, (slice(None), slice(None), pos), contrib)
-    return np.ascontiguousarray(dxp[:, :, pad:pad + L_in], dtype=F32)
+    dyl = np.ascontiguousarray(dy.transpose(0, 2, 1)).reshape(B * Lout, Co)
+    wt = np.ascontiguousarray(w.transpose(2, 0, 1))          # [k, Co, Ci]
+    dxp = np.zeros((B, L_in + 2 * pad + stride, Ci), F32)
+    for tap in range(k):                                     # positions lo*stride+tap are distinct per tap
+        dxp[:, tap:tap + (Lout - 1) * stride + 1:stride, :] += (dyl @ wt[tap]).reshape(B, Lout, Ci)
+    return np.ascontiguousarray(dxp[:, pad:pad + L_in, :].transpose(0, 2, 1), dtype=F32)
 
 
 def conv_transpose1d(x, w, b, stride=2, pad=1):
@@ -91,12 +89,13 @@ def conv_transpose1d(x, w, b, stride=2, pad=1):
     Ci, Co, k = w.shape
     B, _, L = x.shape
     Lfull = (L - 1) * stride + k
-    y = np.zeros((B, Co, Lfull), F32)
+    xl = np.ascontiguousarray(x.transpose(0, 2, 1)).reshape(B * L, Ci)
+    wt = np.ascontiguousarray(w.transpose(2, 0, 1))          # [k, Ci, Co]
+    y = np.zeros((B, Lfull, Co), F32)
     for tap in range(k):
-        contrib = np.einsum('bil,io->bol', x, w[:, :, tap]).astype(F32)
-        y[:, :, tap:tap + (L - 1) * stride + 1:stride] += contrib
-    y = y[:, :, pad:Lfull - pad]
-    return np.ascontiguousarray(y + b[None, :, None], dtype=F32)
+        y[:, tap:tap + (L - 1) * stride + 1:stride, :] += (xl @ wt[tap]).reshape(B, L, Co)
+    y = y[:, pad:Lfull - pad, :] + b
+    return np.ascontiguousarray(y.transpose(0, 2, 1), dtype=F32)
 
 
 def group_norm(x, gamma, beta, groups=8, eps=1e-5):

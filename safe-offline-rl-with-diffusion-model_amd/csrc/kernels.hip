@@ -21,13 +21,21 @@ namespace trebi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float softplus_f(float x) {       // torch softplus, threshold 20
-  return x > 20.f ? x : log1pf(expf(x));
+// Mish and its derivative from ONE exponential: with e = exp(x), n = e*(e+2):
+//   tanh(softplus(x)) = n/(n+2),   sigmoid(x) = e/(1+e).
+// torch's softplus switches to the identity above 20 (tanh(20) == 1 in f32), so x > 20 returns x / 1.
+__device__ __forceinline__ float mish_f(float x) {
+  if (x > 20.f) return x;
+  float e = __expf(x);
+  float n = e * (e + 2.f);
+  return x * __fdividef(n, n + 2.f);
 }
-__device__ __forceinline__ float mish_f(float x) { return x * tanhf(softplus_f(x)); }
 __device__ __forceinline__ float mish_grad_f(float x) {
-  float th = tanhf(softplus_f(x));
-  float sg = 1.f / (1.f + expf(-x));
+  if (x > 20.f) return 1.f;
+  float e = __expf(x);
+  float n = e * (e + 2.f);
+  float th = __fdividef(n, n + 2.f);
+  float sg = __fdividef(e, 1.f + e);
   return th + x * sg * (1.f - th * th);
 }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -36,11 +44,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// n / d for the small index ranges used here (host guarantees n * d < 2^32): one mul-hi.
+struct FastDiv {
+  unsigned d, m;
+  __device__ explicit FastDiv(unsigned dd) : d(dd), m(dd > 1 ? 0xFFFFFFFFu / dd + 1u : 0u) {}
+  __device__ __forceinline__ unsigned div(unsigned n) const { return d == 1 ? n : __umulhi(n, m); }
+};
+
 // ----------------------------------------------------------------------------------
 // LDS carve (floats), shared between host sizing and the kernel
+//   [ stage: slab | slab2 | yslab ]  (dead after the K loop; aliased by the split-K partials)
+//   [ restile | colp | tbrow | pstat | stat ]
 // ----------------------------------------------------------------------------------
 struct Carve {
-  int R, ldA, nA, ld2, n2, TM, TN, TNp, red1, body, nstat;
+  int R, ldA, nA, ld2, n2, nY, TM, TN, TNp, red1, body, nres, ncolp, ntb, npstat, nstat, total;
 };
 __host__ __device__ inline Carve make_carve(const ConvP& p, int MI, int NI, int NG, int KS, int S) {
   Carve c;
@@ -49,25 +66,61 @@ __host__ __device__ inline Carve make_carve(const ConvP& p, int MI, int NI, int 
   c.nA = S * c.R * c.ldA;
   c.ld2 = p.x2 ? p.Cin2_p + 4 : 0;
   c.n2 = p.x2 ? S * p.Lout * c.ld2 : 0;
+  c.nY = p.pro ? S * p.Lin * c.ldA : 0;
   c.TM = 16 * MI;
   c.TN = 16 * NI * NG;
   c.TNp = c.TN + 4;
   c.red1 = KS * c.TM * c.TNp;
   int red = c.red1 * (p.x2 ? 2 : 1);
-  int stage = c.nA + c.n2;
+  int stage = c.nA + c.n2 + c.nY;
   c.body = ((stage > red ? stage : red) + 3) & ~3;
+  c.nres = p.res ? c.TM * c.TNp : 0;
+  c.ncolp = 4 * c.TN;
+  c.ntb = p.tbias ? S * c.TN : 0;
+  c.npstat = p.pro ? 4 * S * GN_GROUPS : 0;       // (mean, rstd) then (m1, m2)
   int ginst = p.gn ? c.TN / p.gch : 0;
-  c.nstat = 2 * S * (ginst > GN_GROUPS ? ginst : GN_GROUPS);
+  c.nstat = 2 * S * (ginst > 1 ? ginst : 1);
+  c.total = c.body + c.nres + c.ncolp + c.ntb + c.npstat + c.nstat;
   return c;
 }
 
 size_t conv_lds_bytes(const ConvP& p, const Tile& tl) {
   Carve c = make_carve(p, tl.MI, tl.NI, tl.NG, tl.KS, tl.S);
-  return (size_t)(c.body + c.nstat) * sizeof(float);
+  return (size_t)c.total * sizeof(float);
 }
 
+// Rows of a [rows, C] global tensor -> LDS rows of stride ld (zero filled past C / invalid rows).
+// rowmap(row, &valid) gives the global row offset (in floats).
+template <typename RowFn>
+__device__ __forceinline__ void stage_rows(float* dst, int ld, int nrows, int C, int C_p, const float* src,
+                                           int ldsrc, int tid, int nthr, RowFn rowfn) {
+  const int c4n = C_p >> 2;
+  const FastDiv dv(c4n);
+  const int total = nrows * c4n;
+  const bool vec = ((ldsrc & 3) == 0) && ((C & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
+  for (int idx = tid; idx < total; idx += nthr) {
+    int row = dv.div(idx), c4 = idx - row * c4n;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    long off = rowfn(row);
+    if (off >= 0) {
+      const float* sp = src + off + 4 * c4;
+      if (vec) {
+        if (4 * c4 < C) v = *(const f32x4*)sp;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * c4 + e < C) v[e] = sp[e];
+      }
+    }
+    *(f32x4*)&dst[row * ld + 4 * c4] = v;
+  }
+}
+
+// WB = reduction steps whose weights a wave preloads into registers before anything else, so the
+// weight fetch overlaps the activation staging (one memory latency per kernel instead of one per step).
 template <int MI, int NI>
 __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int NG, int KS) {
+  constexpr int WB = (NI == 1) ? (MI <= 2 ? 24 : 16) : 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ConvP& p = L.p[blockIdx.z];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -77,124 +130,20 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
   const Carve cv = make_carve(p, MI, NI, NG, KS, S);
   const int R = cv.R, ldA = cv.ldA, ld2 = cv.ld2, TM = cv.TM, TN = cv.TN, TNp = cv.TNp;
   float* slab = smem;
-  float* slab2 = smem + cv.nA;
-  float* stat = smem + cv.body;
+  float* slab2 = slab + cv.nA;
+  float* yslab = slab2 + cv.n2;
+  float* restile = smem + cv.body;
+  float* colp = restile + cv.nres;          // [4][TN]: bias, gamma, beta, bias2
+  float* tbrow = colp + cv.ncolp;           // [S][TN]
+  float* pstat = tbrow + cv.ntb;            // [S*8][2] mean,rstd ; then [S*8][2] m1,m2
+  float* stat = pstat + cv.npstat;
   const int b0 = blockIdx.x * S;
   const int n0 = blockIdx.y * TN;
   const int B = p.B, Lin = p.Lin, Lout = p.Lout;
   const int li_min = p.tap_lo - p.pad;
+  const FastDiv dLout(Lout), dTN(TN);
 
-  // ---- stage the primary source: S whole candidates, all input channels, zero halo ----
-  {
-    const int c4n = p.Cin_p >> 2;
-    const int total = S * R * c4n;
-    const bool vec = ((p.ldx & 3) == 0) && ((p.Cin & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
-    for (int idx = tid; idx < total; idx += nthr) {
-      int row = idx / c4n, c4 = idx - row * c4n;
-      int s = row / R, j = row - s * R;
-      int li = j + li_min, b = b0 + s;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b < B && li >= 0 && li < Lin) {
-        const float* src = p.x + ((size_t)b * Lin + li) * p.ldx + 4 * c4;
-        if (vec) {
-          if (4 * c4 < p.Cin) v = *(const f32x4*)src;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (4 * c4 + e < p.Cin) v[e] = src[e];
-        }
-      }
-      *(f32x4*)&slab[row * ldA + 4 * c4] = v;
-    }
-  }
-  if (p.x2) {
-    const int c4n = p.Cin2_p >> 2;
-    const int total = S * Lout * c4n;
-    const bool vec = ((p.ldx2 & 3) == 0) && ((p.Cin2 & 3) == 0) && ((((uintptr_t)p.x2) & 15) == 0);
-    for (int idx = tid; idx < total; idx += nthr) {
-      int row = idx / c4n, c4 = idx - row * c4n;
-      int s = row / Lout, lo = row - s * Lout;
-      int b = b0 + s;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b < B) {
-        const float* src = p.x2 + ((size_t)b * Lout + lo) * p.ldx2 + 4 * c4;
-        if (vec) {
-          if (4 * c4 < p.Cin2) v = *(const f32x4*)src;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (4 * c4 + e < p.Cin2) v[e] = src[e];
-        }
-      }
-      *(f32x4*)&slab2[row * ld2 + 4 * c4] = v;
-    }
-  }
-  __syncthreads();
-
-  // ---- prologue: GroupNorm+Mish backward of the producing Conv1dBlock, in LDS ----------
-  //   xhat = (y-mean)*rstd; z = gamma*xhat+beta; dxhat = dA*mish'(z)*gamma
-  //   dY = rstd*(dxhat - mean_g(dxhat) - xhat*mean_g(dxhat*xhat))
-  if (p.pro) {
-    const int C = p.Cin, gch = p.pro_gch;
-    const int per = Lin * C;
-    const int total = S * per;
-    for (int idx = tid; idx < total; idx += nthr) {
-      int s = idx / per, r = idx - s * per;
-      int li = r / C, c = r - li * C;
-      int b = b0 + s;
-      if (b < B) {
-        float y = p.pro_y[((size_t)b * Lin + li) * C + c];
-        const float* st = p.pro_stats + ((size_t)b * GN_GROUPS + c / gch) * 2;
-        float xh = (y - st[0]) * st[1];
-        float ga = p.pro_gamma[c];
-        float z = xh * ga + p.pro_beta[c];
-        float* e = &slab[(s * R + (li - li_min)) * ldA + c];
-        *e = *e * mish_grad_f(z) * ga;
-      }
-    }
-    __syncthreads();
-    const int cnt = Lin * gch;
-    for (int inst = wave; inst < S * GN_GROUPS; inst += nwaves) {
-      int s = inst / GN_GROUPS, gi = inst - s * GN_GROUPS;
-      int b = b0 + s;
-      float s1 = 0.f, s2 = 0.f;
-      if (b < B) {
-        const float* st = p.pro_stats + ((size_t)b * GN_GROUPS + gi) * 2;
-        float mean = st[0], rstd = st[1];
-        for (int e = lane; e < cnt; e += 64) {
-          int li = e / gch, c = gi * gch + (e - li * gch);
-          float y = p.pro_y[((size_t)b * Lin + li) * C + c];
-          float d = slab[(s * R + (li - li_min)) * ldA + c];
-          s1 += d;
-          s2 += d * ((y - mean) * rstd);
-        }
-      }
-      s1 = wave_sum(s1);
-      s2 = wave_sum(s2);
-      if (lane == 0) {
-        stat[2 * inst] = s1 / (float)cnt;
-        stat[2 * inst + 1] = s2 / (float)cnt;
-      }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < total; idx += nthr) {
-      int s = idx / per, r = idx - s * per;
-      int li = r / C, c = r - li * C;
-      int b = b0 + s;
-      if (b < B) {
-        int gi = c / gch;
-        float y = p.pro_y[((size_t)b * Lin + li) * C + c];
-        const float* st = p.pro_stats + ((size_t)b * GN_GROUPS + gi) * 2;
-        float rstd = st[1];
-        float xh = (y - st[0]) * rstd;
-        float* e = &slab[(s * R + (li - li_min)) * ldA + c];
-        *e = rstd * (*e - stat[2 * (s * GN_GROUPS + gi)] - xh * stat[2 * (s * GN_GROUPS + gi) + 1]);
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- implicit GEMM on the f32 matrix cores --------------------------------------------
+  // ---- wave geometry + weight preload (registers) -------------------------------------------
   // v_mfma_f32_16x16x4_f32: lane l feeds A[row l&15][k l>>4] and B[k l>>4][col l&15].  The
   // reduction index is permuted so that lane-group g = l>>4 owns channels 16*kk+4g .. +3 of
   // step kk and the four MFMAs of the step consume one float4 of A (LDS) and one of B (global).
@@ -208,12 +157,131 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
   const int k_begin = ks * chunk;
   const int k_end = (k_begin + chunk < KK) ? k_begin + chunk : KK;
   const int ncol = n0 + ng * NI * 16 + lr;
+  const float* wq = p.w + ((size_t)g * p.Npad + ncol) * 4;
+  const size_t wstep = (size_t)p.Npad * 16;     // floats per kk step
+  f32x4 wreg[WB][NI];
+#pragma unroll
+  for (int u = 0; u < WB; ++u)
+    if (k_begin + u < k_end) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wq + (k_begin + u) * wstep + ni * 64);
+    }
 
+  // ---- stage everything this workgroup reads from global, in one burst -------------------------
+  {
+    const FastDiv dR(R);
+    stage_rows(slab, ldA, S * R, p.Cin, p.Cin_p, p.x, p.ldx, tid, nthr, [&](int row) -> long {
+      int s = dR.div(row), j = row - s * R;
+      int li = j + li_min, b = b0 + s;
+      return (b < B && li >= 0 && li < Lin) ? ((long)b * Lin + li) * p.ldx : -1;
+    });
+  }
+  if (p.x2)
+    stage_rows(slab2, ld2, S * Lout, p.Cin2, p.Cin2_p, p.x2, p.ldx2, tid, nthr, [&](int row) -> long {
+      int s = dLout.div(row);
+      return (b0 + s < B) ? ((long)b0 * Lout + row) * p.ldx2 : -1;
+    });
+  if (p.pro) {
+    const FastDiv dLin(Lin);
+    stage_rows(yslab, ldA, S * Lin, p.Cin, p.Cin_p, p.pro_y, p.Cin, tid, nthr, [&](int row) -> long {
+      int s = dLin.div(row);
+      return (b0 + s < B) ? ((long)b0 * Lin + row) * p.Cin : -1;
+    });
+    for (int i = tid; i < S * GN_GROUPS * 2; i += nthr)
+      pstat[i] = (b0 + i / (GN_GROUPS * 2) < B) ? p.pro_stats[(size_t)b0 * GN_GROUPS * 2 + i] : 0.f;
+  }
+  if (p.res)
+    for (int e = tid; e < TM * TN; e += nthr) {
+      int row = dTN.div(e), col = e - row * TN;
+      int s = dLout.div(row);
+      int n = n0 + col;
+      restile[row * TNp + col] = (s < S && b0 + s < B && n < p.N) ? p.res[((size_t)b0 * Lout + row) * p.ldres + n] : 0.f;
+    }
+  for (int c = tid; c < TN; c += nthr) {
+    int n = n0 + c;
+    bool ok = n < p.N;
+    colp[c] = (ok && p.bias) ? p.bias[n] : 0.f;
+    colp[TN + c] = (ok && p.gn) ? p.gamma[n] : 1.f;
+    colp[2 * TN + c] = (ok && p.gn) ? p.beta[n] : 0.f;
+    colp[3 * TN + c] = (ok && p.bias2) ? p.bias2[n] : 0.f;
+  }
+  if (p.tbias)
+    for (int e = tid; e < S * TN; e += nthr) {
+      int s = dTN.div(e), c = e - s * TN;
+      int b = b0 + s, n = n0 + c;
+      float v = 0.f;
+      if (b < B && n < p.N) {
+        long long tt = p.t[b];
+        tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
+        v = p.tbias[(size_t)tt * p.N + n];
+      }
+      tbrow[e] = v;
+    }
+  __syncthreads();
+
+  // ---- prologue: GroupNorm+Mish backward of the producing Conv1dBlock, in LDS ----------
+  //   xhat = (y-mean)*rstd; z = gamma*xhat+beta; dxhat = dA*mish'(z)*gamma
+  //   dY = rstd*(dxhat - mean_g(dxhat) - xhat*mean_g(dxhat*xhat))
+  if (p.pro) {
+    const int C = p.Cin, gch = p.pro_gch;
+    const FastDiv dC(C), dG(gch);
+    const int rows = S * Lin;
+    const int total = rows * C;
+    const FastDiv dLin(Lin);
+    for (int idx = tid; idx < total; idx += nthr) {
+      int row = dC.div(idx), c = idx - row * C;
+      int s = dLin.div(row), li = row - s * Lin;
+      if (b0 + s < B) {
+        int gi = dG.div(c);
+        float mean = pstat[2 * (s * GN_GROUPS + gi)], rstd = pstat[2 * (s * GN_GROUPS + gi) + 1];
+        float xh = (yslab[row * ldA + c] - mean) * rstd;
+        float ga = p.pro_gamma[c];
+        float z = xh * ga + p.pro_beta[c];
+        float* e = &slab[(s * R + (li - li_min)) * ldA + c];
+        *e = *e * mish_grad_f(z) * ga;
+        yslab[row * ldA + c] = xh;
+      }
+    }
+    __syncthreads();
+    const int cnt = Lin * gch;
+    float* pm = pstat + 2 * S * GN_GROUPS;
+    for (int inst = wave; inst < S * GN_GROUPS; inst += nwaves) {
+      int s = inst / GN_GROUPS, gi = inst - s * GN_GROUPS;
+      float s1 = 0.f, s2 = 0.f;
+      if (b0 + s < B)
+        for (int e = lane; e < cnt; e += 64) {
+          int li = dG.div(e), c = gi * gch + (e - li * gch);
+          float d = slab[(s * R + (li - li_min)) * ldA + c];
+          s1 += d;
+          s2 += d * yslab[(s * Lin + li) * ldA + c];
+        }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (lane == 0) {
+        pm[2 * inst] = s1 / (float)cnt;
+        pm[2 * inst + 1] = s2 / (float)cnt;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < total; idx += nthr) {
+      int row = dC.div(idx), c = idx - row * C;
+      int s = dLin.div(row), li = row - s * Lin;
+      if (b0 + s < B) {
+        int gi = dG.div(c);
+        float rstd = pstat[2 * (s * GN_GROUPS + gi) + 1];
+        float* e = &slab[(s * R + (li - li_min)) * ldA + c];
+        *e = rstd * (*e - pm[2 * (s * GN_GROUPS + gi)] - yslab[row * ldA + c] * pm[2 * (s * GN_GROUPS + gi) + 1]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- implicit GEMM on the f32 matrix cores --------------------------------------------
   int rowA[MI], row2[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     int r = mi * 16 + lr;
-    int s = r / Lout, lo = r - s * Lout;
+    int s = dLout.div(r), lo = r - s * Lout;
     bool ok = s < S;
     rowA[mi] = ok ? (s * R + lo * p.stride) * ldA + 4 * g : 4 * g;
     row2[mi] = ok ? (s * Lout + lo) * ld2 + 4 * g : 4 * g;
@@ -226,43 +294,46 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
       acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-  const float* wq = p.w + ((size_t)g * p.Npad + ncol) * 4;
-  const size_t wstep = (size_t)p.Npad * 16;     // floats per kk step
-  {
-    const int e1 = k_end < KK1 ? k_end : KK1;
-    int tau = k_begin / cbpt, cb = k_begin - tau * cbpt;
-
-    for (int kk = k_begin; kk < e1; ++kk) {
-      f32x4 a[MI], bq[NI];
-      const int aoff = tau * ldA + cb * 16;
+  for (int base = k_begin; base < k_end; base += WB) {
+    if (base != k_begin) {                      // later blocks (large reductions only): reload the registers
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bq[ni] = *(const f32x4*)(wq + kk * wstep + ni * 64);
+      for (int u = 0; u < WB; ++u)
+        if (base + u < k_end) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], bq[ni][j], acc[mi][ni], 0, 0, 0);
-      if (++cb == cbpt) { cb = 0; ++tau; }
+          for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wq + (base + u) * wstep + ni * 64);
+        }
     }
-    const int s2 = k_begin > KK1 ? k_begin : KK1;
-    for (int kk = s2; kk < k_end; ++kk) {
-      f32x4 a[MI], bq[NI];
-      const int aoff = (kk - KK1) * 16;
+    int tau = base / cbpt, cb = base - tau * cbpt;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bq[ni] = *(const f32x4*)(wq + kk * wstep + ni * 64);
+    for (int u = 0; u < WB; ++u) {
+      const int kk = base + u;
+      if (kk < k_end) {
+        f32x4 a[MI];
+        if (kk < KK1) {
+          const int aoff = tau * ldA + cb * 16;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab2[row2[mi] + aoff];
+          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc2[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], bq[ni][j], acc2[mi][ni], 0, 0, 0);
+              for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc[mi][ni], 0, 0, 0);
+          if (++cb == cbpt) { cb = 0; ++tau; }
+        } else {
+          const int aoff = (kk - KK1) * 16;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab2[row2[mi] + aoff];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc2[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc2[mi][ni], 0, 0, 0);
+        }
+      }
     }
   }
   __syncthreads();     // every wave is done with the staged activations; LDS becomes the reduce buffer
@@ -285,40 +356,38 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
   // ---- reduce over the K split, add bias; keep the tile in slot 0 ---------------------------
   const int tile_elems = TM * TN;
   for (int e = tid; e < tile_elems; e += nthr) {
-    int row = e / TN, col = e - row * TN;
-    int n = n0 + col;
-    float v = 0.f, v2 = 0.f;
+    int row = dTN.div(e), col = e - row * TN;
+    float v = colp[col], v2 = colp[3 * TN + col];
     for (int k = 0; k < KS; ++k) v += red[(k * TM + row) * TNp + col];
-    if (p.bias && n < p.N) v += p.bias[n];
     red[row * TNp + col] = v;
     if (p.x2) {
       for (int k = 0; k < KS; ++k) v2 += red2[(k * TM + row) * TNp + col];
-      if (p.bias2 && n < p.N) v2 += p.bias2[n];
       red2[row * TNp + col] = v2;
     }
     if (p.save_y) {
-      int s = row / Lout, lo = row - s * Lout;
-      int b = b0 + s;
-      if (s < S && b < B && n < p.N) p.save_y[((size_t)b * Lout + lo) * p.N + n] = v;
+      int s = dLout.div(row);
+      int n = n0 + col;
+      if (s < S && b0 + s < B && n < p.N) p.save_y[((size_t)b0 * Lout + row) * p.N + n] = v;
     }
   }
   __syncthreads();
 
   // ---- GroupNorm statistics: one wave per (candidate, group), two passes over LDS ------------
-  const int gpt = p.gn ? TN / p.gch : 0;     // groups in this column tile
+  const int gpt = p.gn ? TN / p.gch : 1;     // groups in this column tile
   if (p.gn) {
     const int gch = p.gch, cnt = Lout * gch;
+    const FastDiv dG(gch);
     for (int inst = wave; inst < S * gpt; inst += nwaves) {
       int s = inst / gpt, gi = inst - s * gpt;
       float sum = 0.f;
       for (int e = lane; e < cnt; e += 64) {
-        int lo = e / gch, c = e - lo * gch;
+        int lo = dG.div(e), c = e - lo * gch;
         sum += red[(s * Lout + lo) * TNp + gi * gch + c];
       }
       float mean = wave_sum(sum) / (float)cnt;
       float sq = 0.f;
       for (int e = lane; e < cnt; e += 64) {
-        int lo = e / gch, c = e - lo * gch;
+        int lo = dG.div(e), c = e - lo * gch;
         float d = red[(s * Lout + lo) * TNp + gi * gch + c] - mean;
         sq += d * d;
       }
@@ -339,29 +408,27 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
   }
 
   // ---- normalise, Mish, time bias, residuals, store ----------------------------------------------
+  const FastDiv dGe(p.gn ? p.gch : 1), dOs(p.osplit > 0 ? p.osplit : 1);
   for (int e = tid; e < tile_elems; e += nthr) {
-    int row = e / TN, col = e - row * TN;
-    int s = row / Lout, lo = row - s * Lout;
+    int row = dTN.div(e), col = e - row * TN;
+    int s = dLout.div(row);
     int b = b0 + s, n = n0 + col;
     if (s >= S || b >= B || n >= p.N) continue;
     float v = red[row * TNp + col];
     if (p.gn) {
-      int inst = s * gpt + col / p.gch;
-      v = (v - stat[2 * inst]) * stat[2 * inst + 1] * p.gamma[n] + p.beta[n];
+      int inst = s * gpt + dGe.div(col);
+      v = (v - stat[2 * inst]) * stat[2 * inst + 1] * colp[TN + col] + colp[2 * TN + col];
       v = mish_f(v);
     }
-    if (p.tbias) {
-      long long tt = p.t[b];
-      tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
-      v += p.tbias[(size_t)tt * p.N + n];
-    }
+    if (p.tbias) v += tbrow[s * TN + col];
     if (p.x2) v += red2[row * TNp + col];
-    if (p.res) v += p.res[((size_t)b * Lout + lo) * p.ldres + n];
+    if (p.res) v += restile[row * TNp + col];
+    size_t orow = (size_t)b0 * Lout + row;
     if (p.osplit > 0) {
-      int ph = n / p.osplit, co = n - ph * p.osplit;
-      p.out[(((size_t)b * Lout + lo) * 2 + ph) * p.ldo + co] = v;
+      int ph = dOs.div(n), co = n - ph * p.osplit;
+      p.out[(orow * 2 + ph) * p.ldo + co] = v;
     } else {
-      p.out[((size_t)b * Lout + lo) * p.ldo + n] = v;
+      p.out[orow * p.ldo + n] = v;
     }
   }
 }

@@ -331,11 +331,24 @@ struct Builder {
                      std::to_string(numel)};
     return it->second.first;
   }
+  // bump allocation out of a few large device chunks: packed weights of consecutive layers sit next
+  // to each other (fewer TLB misses for kernels that each touch a different layer)
+  char* chunk = nullptr;
+  size_t chunk_left = 0;
   float* dalloc(size_t n) {
-    void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)) != hipSuccess) throw BadShape{"hipMalloc failed"};
-    net->allocs.push_back(p);
-    return (float*)p;
+    size_t bytes = (std::max<size_t>(n, 1) * sizeof(float) + 255) / 256 * 256;
+    if (bytes > chunk_left) {
+      size_t sz = std::max<size_t>(bytes, (size_t)16 << 20);
+      void* p = nullptr;
+      if (hipMalloc(&p, sz) != hipSuccess) throw BadShape{"hipMalloc failed"};
+      net->allocs.push_back(p);
+      chunk = (char*)p;
+      chunk_left = sz;
+    }
+    float* r = (float*)chunk;
+    chunk += bytes;
+    chunk_left -= bytes;
+    return r;
   }
   const float* upload(const float* h, size_t n) {
     float* d = dalloc(n);
@@ -849,6 +862,8 @@ Tile choose_tile(const Op& op, int B) {
     p.Lout = op.Lout; p.stride = op.stride; p.ntaps = op.ntaps; p.Cin_p = op.Cin_p;
     p.x2 = op.src2.id != NONE ? (const float*)1 : nullptr;
     p.Cin2_p = op.Cin2_p; p.gn = op.gn; p.gch = op.gn ? op.gnw.gch : 1;
+    p.Lin = op.Lin; p.pro = op.pro ? 1 : 0; p.tbias = op.tbias;
+    p.res = op.res.id != NONE ? (const float*)1 : nullptr;
     Tile tt{mi_for(s), ni, ng, ks, s};
     return conv_lds_bytes(p, tt);
   };
