@@ -36,24 +36,32 @@ struct ConvP {
   int gn, gch;
   const float* gamma;
   const float* beta;
-  float* save_y;                   // [B*Lout, N] conv output before GroupNorm (for the backward)
+  float* save_y;                   // [B*Lout, N] normalised conv output xhat (for the backward)
+  float* save_g;                   // [B*Lout, N] mish'(gamma*xhat+beta)*gamma (for the backward)
   float* save_stats;               // [B, 8, 2] (mean, rstd)
   const float* tbias;              // [T, N] or null
   const long long* t;              // [B]
+  int t_uniform;                   // >= 0: every candidate is at this timestep (skips the t[b] load)
   int T;
   const float* res;                // identity residual or null
   int ldres;
   // prologue: GroupNorm+Mish backward applied to the primary source
   int pro, pro_gch;
-  const float* pro_y;              // [B*Lin, Cin]
+  const float* pro_y;              // [B*Lin, Cin] xhat saved by the forward
+  const float* pro_g;              // [B*Lin, Cin] mish'(z)*gamma saved by the forward
   const float* pro_stats;          // [B, 8, 2]
-  const float* pro_gamma;
-  const float* pro_beta;
   int B;
+};
+
+// Magic multipliers for the index divisions the kernel does (n / d == umulhi(n, m) for n*d < 2^32),
+// computed once on the host so no workgroup spends instructions on integer division.
+struct ConvAux {
+  unsigned mLout, mTN, mR, mLin, mGch, mPGch, mGpt, mOs, mC4, mC4b, mNth16;
 };
 
 struct ConvLaunch {
   ConvP p[2];                      // blockIdx.z selects (reward / cost net run in one launch)
+  ConvAux aux;                     // both nets of a launch have identical shapes
 };
 
 struct Tile {

@@ -21,6 +21,22 @@ namespace trebi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef TREBI_STAMPS          // diagnostic build only: per-phase cycle stamps of workgroup (0,0,0), wave 0
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i)                                                                                  \
+  do {                                                                                            \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {              \
+      g_stamps[i] = __builtin_amdgcn_s_memtime();                                                 \
+      g_stamps[16 + i] = __builtin_amdgcn_s_memrealtime();                                        \
+    }                                                                                             \
+  } while (0)
+extern "C" int trebi_debug_read_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#else
+#define STAMP(i)
+#endif
+
 // Mish and its derivative from ONE exponential: with e = exp(x), n = e*(e+2):
 //   tanh(softplus(x)) = n/(n+2),   sigmoid(x) = e/(1+e).
 // torch's softplus switches to the identity above 20 (tanh(20) == 1 in f32), so x > 20 returns x / 1.
@@ -38,26 +54,37 @@ __device__ __forceinline__ float mish_grad_f(float x) {
   float sg = __fdividef(e, 1.f + e);
   return th + x * sg * (1.f - th * th);
 }
+__device__ __forceinline__ void mish_both(float x, float* m, float* dm) {
+  if (x > 20.f) { *m = x; *dm = 1.f; return; }
+  float e = __expf(x);
+  float n = e * (e + 2.f);
+  float th = __fdividef(n, n + 2.f);
+  float sg = __fdividef(e, 1.f + e);
+  *m = x * th;
+  *dm = th + x * sg * (1.f - th * th);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
-// n / d for the small index ranges used here (host guarantees n * d < 2^32): one mul-hi.
+// n / d for the small index ranges used here (host guarantees n * d < 2^32): one mul-hi with a
+// host-computed multiplier m = ceil(2^32 / d) (m == 0 encodes d == 1).
 struct FastDiv {
   unsigned d, m;
-  __device__ explicit FastDiv(unsigned dd) : d(dd), m(dd > 1 ? 0xFFFFFFFFu / dd + 1u : 0u) {}
-  __device__ __forceinline__ unsigned div(unsigned n) const { return d == 1 ? n : __umulhi(n, m); }
+  __device__ FastDiv(unsigned dd, unsigned mm) : d(dd), m(mm) {}
+  __device__ __forceinline__ unsigned div(unsigned n) const { return m == 0 ? n : __umulhi(n, m); }
 };
+static inline unsigned magic_of(unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
 
 // ----------------------------------------------------------------------------------
 // LDS carve (floats), shared between host sizing and the kernel
 //   [ stage: slab | slab2 | yslab ]  (dead after the K loop; aliased by the split-K partials)
-//   [ restile | colp | tbrow | pstat | stat ]
+//   [ restile | colp | tbrow | pstat ]
 // ----------------------------------------------------------------------------------
 struct Carve {
-  int R, ldA, nA, ld2, n2, nY, TM, TN, TNp, red1, body, nres, ncolp, ntb, npstat, nstat, total;
+  int R, ldA, nA, ld2, n2, nY, TM, TN, TNp, red1, body, nres, ncolp, ntb, npstat, total;
 };
 __host__ __device__ inline Carve make_carve(const ConvP& p, int MI, int NI, int NG, int KS, int S) {
   Carve c;
@@ -77,10 +104,8 @@ __host__ __device__ inline Carve make_carve(const ConvP& p, int MI, int NI, int 
   c.nres = p.res ? c.TM * c.TNp : 0;
   c.ncolp = 4 * c.TN;
   c.ntb = p.tbias ? S * c.TN : 0;
-  c.npstat = p.pro ? 4 * S * GN_GROUPS : 0;       // (mean, rstd) then (m1, m2)
-  int ginst = p.gn ? c.TN / p.gch : 0;
-  c.nstat = 2 * S * (ginst > 1 ? ginst : 1);
-  c.total = c.body + c.nres + c.ncolp + c.ntb + c.npstat + c.nstat;
+  c.npstat = p.pro ? 2 * S * GN_GROUPS : 0;
+  c.total = c.body + c.nres + c.ncolp + c.ntb + c.npstat;
   return c;
 }
 
@@ -89,31 +114,69 @@ size_t conv_lds_bytes(const ConvP& p, const Tile& tl) {
   return (size_t)c.total * sizeof(float);
 }
 
-// Rows of a [rows, C] global tensor -> LDS rows of stride ld (zero filled past C / invalid rows).
-// rowmap(row, &valid) gives the global row offset (in floats).
-template <typename RowFn>
-__device__ __forceinline__ void stage_rows(float* dst, int ld, int nrows, int C, int C_p, const float* src,
-                                           int ldsrc, int tid, int nthr, RowFn rowfn) {
-  const int c4n = C_p >> 2;
-  const FastDiv dv(c4n);
-  const int total = nrows * c4n;
-  const bool vec = ((ldsrc & 3) == 0) && ((C & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
-  for (int idx = tid; idx < total; idx += nthr) {
-    int row = dv.div(idx), c4 = idx - row * c4n;
+// A [rows, C] global tensor -> LDS rows of stride ld (zero filled past C and for invalid rows);
+// optionally multiplied elementwise by a second [rows, C] tensor on the way.
+struct RowStream {
+  const float* src;
+  const float* mul;          // dense [.., C] or null
+  float* dst;
+  int ld, C, c4n, total;
+  bool vec, vecm;
+  FastDiv dv;
+  __device__ RowStream(float* dst_, int ld_, int nrows, int C_, int C_p, const float* src_, int ldsrc_,
+                       const float* mul_, unsigned magic)
+      : src(src_), mul(mul_), dst(dst_), ld(ld_), C(C_), c4n(C_p >> 2), total(nrows * (C_p >> 2)),
+        vec(((ldsrc_ & 3) == 0) && ((C_ & 3) == 0) && ((((uintptr_t)src_) & 15) == 0)),
+        vecm(((C_ & 3) == 0) && ((((uintptr_t)mul_) & 15) == 0)), dv(C_p >> 2, magic) {}
+  __device__ __forceinline__ f32x4 load4(const float* base, bool v4, int c4, long off) const {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    long off = rowfn(row);
-    if (off >= 0) {
-      const float* sp = src + off + 4 * c4;
-      if (vec) {
-        if (4 * c4 < C) v = *(const f32x4*)sp;
-      } else {
+    const float* sp = base + off + 4 * c4;
+    if (v4) {
+      if (4 * c4 < C) v = *(const f32x4*)sp;
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (4 * c4 + e < C) v[e] = sp[e];
+      for (int e = 0; e < 4; ++e)
+        if (4 * c4 + e < C) v[e] = sp[e];
+    }
+    return v;
+  }
+};
+
+// Issue up to U loads per thread before the first LDS write, so one memory round trip covers them.
+// rowfn(row, &moff) returns the source row offset in floats (< 0: zero row) and the multiplier's.
+template <int U, typename RowFn>
+__device__ __forceinline__ void stage_stream(const RowStream& rs, int tid, int nthr, RowFn rowfn) {
+  for (int base = tid; base < rs.total; base += U * nthr) {
+    f32x4 v[U], m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int idx = base + u * nthr;
+      v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      m[u] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      if (idx < rs.total) {
+        int row = rs.dv.div(idx), c4 = idx - row * rs.c4n;
+        long moff = 0;
+        long off = rowfn(row, &moff);
+        if (off >= 0) {
+          v[u] = rs.load4(rs.src, rs.vec, c4, off);
+          if (rs.mul) m[u] = rs.load4(rs.mul, rs.vecm, c4, moff);
+        }
       }
     }
-    *(f32x4*)&dst[row * ld + 4 * c4] = v;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int idx = base + u * nthr;
+      if (idx < rs.total) {
+        int row = rs.dv.div(idx);
+        *(f32x4*)&rs.dst[row * rs.ld + 4 * (idx - row * rs.c4n)] = v[u] * m[u];
+      }
+    }
   }
+}
+
+__device__ __forceinline__ float team_sum(float v, int ts) {
+  for (int o = ts >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
 }
 
 // WB = reduction steps whose weights a wave preloads into registers before anything else, so the
@@ -123,10 +186,10 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
   constexpr int WB = (NI == 1) ? (MI <= 2 ? 24 : 16) : 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ConvP& p = L.p[blockIdx.z];
+  const ConvAux& ax = L.aux;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwaves = nthr >> 6;
   const Carve cv = make_carve(p, MI, NI, NG, KS, S);
   const int R = cv.R, ldA = cv.ldA, ld2 = cv.ld2, TM = cv.TM, TN = cv.TN, TNp = cv.TNp;
   float* slab = smem;
@@ -135,13 +198,13 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
   float* restile = smem + cv.body;
   float* colp = restile + cv.nres;          // [4][TN]: bias, gamma, beta, bias2
   float* tbrow = colp + cv.ncolp;           // [S][TN]
-  float* pstat = tbrow + cv.ntb;            // [S*8][2] mean,rstd ; then [S*8][2] m1,m2
-  float* stat = pstat + cv.npstat;
+  float* pstat = tbrow + cv.ntb;            // [S*8][2] mean, rstd of the producing block
   const int b0 = blockIdx.x * S;
   const int n0 = blockIdx.y * TN;
   const int B = p.B, Lin = p.Lin, Lout = p.Lout;
   const int li_min = p.tap_lo - p.pad;
-  const FastDiv dLout(Lout), dTN(TN);
+  const FastDiv dLout(Lout, ax.mLout), dTN(TN, ax.mTN);
+  STAMP(0);
 
   // ---- wave geometry + weight preload (registers) -------------------------------------------
   // v_mfma_f32_16x16x4_f32: lane l feeds A[row l&15][k l>>4] and B[k l>>4][col l&15].  The
@@ -156,125 +219,158 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
   const int chunk = (KK + KS - 1) / KS;
   const int k_begin = ks * chunk;
   const int k_end = (k_begin + chunk < KK) ? k_begin + chunk : KK;
-  const int ncol = n0 + ng * NI * 16 + lr;
-  const float* wq = p.w + ((size_t)g * p.Npad + ncol) * 4;
-  const size_t wstep = (size_t)p.Npad * 16;     // floats per kk step
+  // uniform base (scalar registers) + one 32-bit per-lane offset: the loads need no per-lane 64-bit math
+  const unsigned wlane = (unsigned)((g * p.Npad + n0 + ng * NI * 16 + lr) * 4);
+  const unsigned wstep = (unsigned)p.Npad * 16u;     // floats per kk step
   f32x4 wreg[WB][NI];
 #pragma unroll
   for (int u = 0; u < WB; ++u)
     if (k_begin + u < k_end) {
+      const float* wu = p.w + (size_t)(k_begin + u) * wstep;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wq + (k_begin + u) * wstep + ni * 64);
+      for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wu + wlane + ni * 64);
     }
+  STAMP(1);
 
-  // ---- stage everything this workgroup reads from global, in one burst -------------------------
+  // ---- stage everything this workgroup reads from global -----------------------------------------
+  // Small per-column / per-candidate parameters first (their loads are issued before the big streams
+  // and complete under them), then the activation streams with 4 loads in flight per thread.
   {
-    const FastDiv dR(R);
-    stage_rows(slab, ldA, S * R, p.Cin, p.Cin_p, p.x, p.ldx, tid, nthr, [&](int row) -> long {
-      int s = dR.div(row), j = row - s * R;
-      int li = j + li_min, b = b0 + s;
-      return (b < B && li >= 0 && li < Lin) ? ((long)b * Lin + li) * p.ldx : -1;
-    });
-  }
-  if (p.x2)
-    stage_rows(slab2, ld2, S * Lout, p.Cin2, p.Cin2_p, p.x2, p.ldx2, tid, nthr, [&](int row) -> long {
-      int s = dLout.div(row);
-      return (b0 + s < B) ? ((long)b0 * Lout + row) * p.ldx2 : -1;
-    });
-  if (p.pro) {
-    const FastDiv dLin(Lin);
-    stage_rows(yslab, ldA, S * Lin, p.Cin, p.Cin_p, p.pro_y, p.Cin, tid, nthr, [&](int row) -> long {
-      int s = dLin.div(row);
-      return (b0 + s < B) ? ((long)b0 * Lin + row) * p.Cin : -1;
-    });
-    for (int i = tid; i < S * GN_GROUPS * 2; i += nthr)
-      pstat[i] = (b0 + i / (GN_GROUPS * 2) < B) ? p.pro_stats[(size_t)b0 * GN_GROUPS * 2 + i] : 0.f;
-  }
-  if (p.res)
-    for (int e = tid; e < TM * TN; e += nthr) {
-      int row = dTN.div(e), col = e - row * TN;
-      int s = dLout.div(row);
-      int n = n0 + col;
-      restile[row * TNp + col] = (s < S && b0 + s < B && n < p.N) ? p.res[((size_t)b0 * Lout + row) * p.ldres + n] : 0.f;
+    float c0 = 0.f, c1 = 1.f, c2 = 0.f, c3 = 0.f;
+    const bool colt = tid < TN;
+    if (colt) {
+      int n = n0 + tid;
+      bool ok = n < p.N;
+      if (ok && p.bias) c0 = p.bias[n];
+      if (ok && p.gn) { c1 = p.gamma[n]; c2 = p.beta[n]; }
+      if (ok && p.bias2) c3 = p.bias2[n];
     }
-  for (int c = tid; c < TN; c += nthr) {
-    int n = n0 + c;
-    bool ok = n < p.N;
-    colp[c] = (ok && p.bias) ? p.bias[n] : 0.f;
-    colp[TN + c] = (ok && p.gn) ? p.gamma[n] : 1.f;
-    colp[2 * TN + c] = (ok && p.gn) ? p.beta[n] : 0.f;
-    colp[3 * TN + c] = (ok && p.bias2) ? p.bias2[n] : 0.f;
-  }
-  if (p.tbias)
-    for (int e = tid; e < S * TN; e += nthr) {
+    // first round of the small per-candidate streams in registers (later rounds, rare, loop below)
+    auto tb_load = [&](int e) -> float {
       int s = dTN.div(e), c = e - s * TN;
       int b = b0 + s, n = n0 + c;
-      float v = 0.f;
-      if (b < B && n < p.N) {
-        long long tt = p.t[b];
-        tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
-        v = p.tbias[(size_t)tt * p.N + n];
-      }
-      tbrow[e] = v;
+      if (b >= B || n >= p.N) return 0.f;
+      long long tt = p.t_uniform >= 0 ? p.t_uniform : p.t[b];
+      tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
+      return p.tbias[(size_t)tt * p.N + n];
+    };
+    auto ps_load = [&](int i) -> float {
+      return (b0 + i / (GN_GROUPS * 2) < B) ? p.pro_stats[(size_t)b0 * GN_GROUPS * 2 + i] : 0.f;
+    };
+    auto res_load = [&](int e) -> float {
+      int row = dTN.div(e), col = e - row * TN;
+      int s = dLout.div(row), n = n0 + col;
+      return (s < S && b0 + s < B && n < p.N) ? p.res[((size_t)b0 * Lout + row) * p.ldres + n] : 0.f;
+    };
+    float tbv[2] = {0.f, 0.f}, psv = 0.f, rv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.tbias) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < S * TN) tbv[u] = tb_load(tid + u * nthr);
     }
-  __syncthreads();
-
-  // ---- prologue: GroupNorm+Mish backward of the producing Conv1dBlock, in LDS ----------
-  //   xhat = (y-mean)*rstd; z = gamma*xhat+beta; dxhat = dA*mish'(z)*gamma
-  //   dY = rstd*(dxhat - mean_g(dxhat) - xhat*mean_g(dxhat*xhat))
-  if (p.pro) {
-    const int C = p.Cin, gch = p.pro_gch;
-    const FastDiv dC(C), dG(gch);
-    const int rows = S * Lin;
-    const int total = rows * C;
-    const FastDiv dLin(Lin);
-    for (int idx = tid; idx < total; idx += nthr) {
-      int row = dC.div(idx), c = idx - row * C;
-      int s = dLin.div(row), li = row - s * Lin;
-      if (b0 + s < B) {
-        int gi = dG.div(c);
-        float mean = pstat[2 * (s * GN_GROUPS + gi)], rstd = pstat[2 * (s * GN_GROUPS + gi) + 1];
-        float xh = (yslab[row * ldA + c] - mean) * rstd;
-        float ga = p.pro_gamma[c];
-        float z = xh * ga + p.pro_beta[c];
-        float* e = &slab[(s * R + (li - li_min)) * ldA + c];
-        *e = *e * mish_grad_f(z) * ga;
-        yslab[row * ldA + c] = xh;
-      }
+    if (p.pro && tid < S * GN_GROUPS * 2) psv = ps_load(tid);
+    if (p.res) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (tid + u * nthr < TM * TN) rv[u] = res_load(tid + u * nthr);
     }
-    __syncthreads();
-    const int cnt = Lin * gch;
-    float* pm = pstat + 2 * S * GN_GROUPS;
-    for (int inst = wave; inst < S * GN_GROUPS; inst += nwaves) {
-      int s = inst / GN_GROUPS, gi = inst - s * GN_GROUPS;
-      float s1 = 0.f, s2 = 0.f;
-      if (b0 + s < B)
-        for (int e = lane; e < cnt; e += 64) {
-          int li = dG.div(e), c = gi * gch + (e - li * gch);
-          float d = slab[(s * R + (li - li_min)) * ldA + c];
-          s1 += d;
-          s2 += d * yslab[(s * Lin + li) * ldA + c];
+    {
+      // with a prologue the source is dL/d(Mish output) and is multiplied by the saved mish'(z)*gamma
+      // on the way in, so the slab holds dL/dxhat
+      const FastDiv dR(R, ax.mR);
+      RowStream rs(slab, ldA, S * R, p.Cin, p.Cin_p, p.x, p.ldx, p.pro ? p.pro_g : nullptr, ax.mC4);
+      stage_stream<4>(rs, tid, nthr, [&](int row, long* moff) -> long {
+        int s = dR.div(row), j = row - s * R;
+        int li = j + li_min, b = b0 + s;
+        if (!(b < B && li >= 0 && li < Lin)) return -1;
+        *moff = ((long)b * Lin + li) * p.Cin;
+        return ((long)b * Lin + li) * p.ldx;
+      });
+    }
+    if (p.x2) {
+      RowStream rs(slab2, ld2, S * Lout, p.Cin2, p.Cin2_p, p.x2, p.ldx2, nullptr, ax.mC4b);
+      stage_stream<2>(rs, tid, nthr, [&](int row, long*) -> long {
+        int s = dLout.div(row);
+        return (b0 + s < B) ? ((long)b0 * Lout + row) * p.ldx2 : -1;
+      });
+    }
+    if (p.pro) {
+      const FastDiv dLin(Lin, ax.mLin);
+      RowStream rs(yslab, ldA, S * Lin, p.Cin, p.Cin_p, p.pro_y, p.Cin, nullptr, ax.mC4);
+      stage_stream<4>(rs, tid, nthr, [&](int row, long*) -> long {
+        int s = dLin.div(row);
+        return (b0 + s < B) ? ((long)b0 * Lin + row) * p.Cin : -1;
+      });
+      if (tid < S * GN_GROUPS * 2) pstat[tid] = psv;
+      for (int i = tid + nthr; i < S * GN_GROUPS * 2; i += nthr) pstat[i] = ps_load(i);
+    }
+    if (colt) {
+      colp[tid] = c0;
+      colp[TN + tid] = c1;
+      colp[2 * TN + tid] = c2;
+      colp[3 * TN + tid] = c3;
+    }
+    if (p.tbias) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < S * TN) tbrow[tid + u * nthr] = tbv[u];
+      for (int e = tid + 2 * nthr; e < S * TN; e += nthr) tbrow[e] = tb_load(e);
+    }
+    if (p.res) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int e = tid + u * nthr;
+        if (e < TM * TN) {
+          int row = dTN.div(e);
+          restile[row * TNp + (e - row * TN)] = rv[u];
         }
-      s1 = wave_sum(s1);
-      s2 = wave_sum(s2);
-      if (lane == 0) {
-        pm[2 * inst] = s1 / (float)cnt;
-        pm[2 * inst + 1] = s2 / (float)cnt;
+      }
+      for (int e = tid + 4 * nthr; e < TM * TN; e += nthr) {
+        int row = dTN.div(e);
+        restile[row * TNp + (e - row * TN)] = res_load(e);
       }
     }
-    __syncthreads();
-    for (int idx = tid; idx < total; idx += nthr) {
-      int row = dC.div(idx), c = idx - row * C;
-      int s = dLin.div(row), li = row - s * Lin;
-      if (b0 + s < B) {
-        int gi = dG.div(c);
-        float rstd = pstat[2 * (s * GN_GROUPS + gi) + 1];
-        float* e = &slab[(s * R + (li - li_min)) * ldA + c];
-        *e = rstd * (*e - pm[2 * (s * GN_GROUPS + gi)] - yslab[row * ldA + c] * pm[2 * (s * GN_GROUPS + gi) + 1]);
+  }
+  STAMP(2);
+  __syncthreads();
+  STAMP(3);
+
+  // Teams of 16 (or 64) lanes each own one (candidate, GroupNorm group): all passes over a group stay
+  // inside the team (shuffle reductions), so neither the prologue nor the epilogue needs a barrier
+  // between its passes.
+  const int nteams16 = nthr >> 4;
+
+  // ---- prologue: GroupNorm backward of the producing Conv1dBlock, in LDS ----------------------
+  //   slab = dxhat = dA * mish'(z) * gamma (multiplied while staging), yslab = xhat (saved by the forward)
+  //   dY = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat * xhat))
+  if (p.pro) {
+    const int gch = p.pro_gch, cnt = Lin * gch, ninst = S * GN_GROUPS;
+    const int ts = (ninst * 4 <= nteams16) ? 64 : 16;
+    const int team = tid / ts, tl = tid & (ts - 1), nteams = nthr / ts;
+    const FastDiv dG(gch, ax.mPGch);
+    for (int inst = team; inst < ninst; inst += nteams) {
+      int s = inst / GN_GROUPS, gi = inst - s * GN_GROUPS;
+      if (b0 + s >= B) continue;
+      const float rstd = pstat[2 * inst + 1];
+      const int ybase = s * Lin * ldA + gi * gch, dbase = (s * R - li_min) * ldA + gi * gch;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+      for (int e = tl; e < cnt; e += ts) {
+        int li = dG.div(e), o = li * ldA + (e - li * gch);
+        float d = slab[dbase + o];
+        s1 += d;
+        s2 += d * yslab[ybase + o];
+      }
+      const float m1 = team_sum(s1, ts) / (float)cnt, m2 = team_sum(s2, ts) / (float)cnt;
+#pragma unroll 4
+      for (int e = tl; e < cnt; e += ts) {
+        int li = dG.div(e), o = li * ldA + (e - li * gch);
+        slab[dbase + o] = rstd * (slab[dbase + o] - m1 - yslab[ybase + o] * m2);
       }
     }
     __syncthreads();
   }
+  STAMP(4);
 
   // ---- implicit GEMM on the f32 matrix cores --------------------------------------------
   int rowA[MI], row2[MI];
@@ -299,8 +395,9 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
 #pragma unroll
       for (int u = 0; u < WB; ++u)
         if (base + u < k_end) {
+          const float* wu = p.w + (size_t)(base + u) * wstep;
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wq + (base + u) * wstep + ni * 64);
+          for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wu + wlane + ni * 64);
         }
     }
     int tau = base / cbpt, cb = base - tau * cbpt;
@@ -336,6 +433,7 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
       }
     }
   }
+  STAMP(5);
   __syncthreads();     // every wave is done with the staged activations; LDS becomes the reduce buffer
 
   // ---- split-K partials -> LDS.  C/D layout: col = lane&15, row = 4*(lane>>4) + reg -------
@@ -352,76 +450,18 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
         if (p.x2) red2[o] = acc2[mi][ni][q];
       }
   __syncthreads();
+  STAMP(6);
 
-  // ---- reduce over the K split, add bias; keep the tile in slot 0 ---------------------------
-  const int tile_elems = TM * TN;
-  for (int e = tid; e < tile_elems; e += nthr) {
-    int row = dTN.div(e), col = e - row * TN;
-    float v = colp[col], v2 = colp[3 * TN + col];
-    for (int k = 0; k < KS; ++k) v += red[(k * TM + row) * TNp + col];
-    red[row * TNp + col] = v;
-    if (p.x2) {
-      for (int k = 0; k < KS; ++k) v2 += red2[(k * TM + row) * TNp + col];
-      red2[row * TNp + col] = v2;
-    }
-    if (p.save_y) {
-      int s = dLout.div(row);
-      int n = n0 + col;
-      if (s < S && b0 + s < B && n < p.N) p.save_y[((size_t)b0 * Lout + row) * p.N + n] = v;
-    }
-  }
-  __syncthreads();
-
-  // ---- GroupNorm statistics: one wave per (candidate, group), two passes over LDS ------------
-  const int gpt = p.gn ? TN / p.gch : 1;     // groups in this column tile
-  if (p.gn) {
-    const int gch = p.gch, cnt = Lout * gch;
-    const FastDiv dG(gch);
-    for (int inst = wave; inst < S * gpt; inst += nwaves) {
-      int s = inst / gpt, gi = inst - s * gpt;
-      float sum = 0.f;
-      for (int e = lane; e < cnt; e += 64) {
-        int lo = dG.div(e), c = e - lo * gch;
-        sum += red[(s * Lout + lo) * TNp + gi * gch + c];
-      }
-      float mean = wave_sum(sum) / (float)cnt;
-      float sq = 0.f;
-      for (int e = lane; e < cnt; e += 64) {
-        int lo = dG.div(e), c = e - lo * gch;
-        float d = red[(s * Lout + lo) * TNp + gi * gch + c] - mean;
-        sq += d * d;
-      }
-      float var = wave_sum(sq) / (float)cnt;
-      float rstd = 1.f / sqrtf(var + GN_EPS);
-      if (lane == 0) {
-        stat[2 * inst] = mean;
-        stat[2 * inst + 1] = rstd;
-        int b = b0 + s;
-        if (p.save_stats && b < B) {
-          float* o = p.save_stats + ((size_t)b * GN_GROUPS + (n0 / gch + gi)) * 2;
-          o[0] = mean;
-          o[1] = rstd;
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- normalise, Mish, time bias, residuals, store ----------------------------------------------
-  const FastDiv dGe(p.gn ? p.gch : 1), dOs(p.osplit > 0 ? p.osplit : 1);
-  for (int e = tid; e < tile_elems; e += nthr) {
-    int row = dTN.div(e), col = e - row * TN;
-    int s = dLout.div(row);
-    int b = b0 + s, n = n0 + col;
-    if (s >= S || b >= B || n >= p.N) continue;
-    float v = red[row * TNp + col];
-    if (p.gn) {
-      int inst = s * gpt + dGe.div(col);
-      v = (v - stat[2 * inst]) * stat[2 * inst + 1] * colp[TN + col] + colp[2 * TN + col];
-      v = mish_f(v);
-    }
+  const FastDiv dOs(p.osplit > 0 ? p.osplit : 1, ax.mOs);
+  // finish one output element: second-source sum, time bias, residual, store
+  auto finish = [&](float v, int s, int row, int col) {
+    int n = n0 + col;
     if (p.tbias) v += tbrow[s * TN + col];
-    if (p.x2) v += red2[row * TNp + col];
+    if (p.x2) {
+      float v2 = colp[3 * TN + col];
+      for (int k = 0; k < KS; ++k) v2 += red2[(k * TM + row) * TNp + col];
+      v += v2;
+    }
     if (p.res) v += restile[row * TNp + col];
     size_t orow = (size_t)b0 * Lout + row;
     if (p.osplit > 0) {
@@ -430,7 +470,69 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L, int S, int
     } else {
       p.out[orow * p.ldo + n] = v;
     }
+  };
+
+  if (p.gn) {
+    // ---- split-K reduce + bias, GroupNorm statistics (two passes), normalise, Mish: per team --------
+    const int gch = p.gch, cnt = Lout * gch, gpt = TN / gch, ninst = S * gpt;
+    const int ts = (ninst * 4 <= nteams16) ? 64 : 16;
+    const int team = tid / ts, tl = tid & (ts - 1), nteams = nthr / ts;
+    const FastDiv dG(gch, ax.mGch), dGpt(gpt, ax.mGpt);
+    for (int inst = team; inst < ninst; inst += nteams) {
+      int s = dGpt.div(inst), gi = inst - s * gpt;
+      const int b = b0 + s;
+      if (b >= B) continue;
+      const int tbase = s * Lout * TNp + gi * gch;
+      float sum = 0.f;
+#pragma unroll 4
+      for (int e = tl; e < cnt; e += ts) {
+        int lo = dG.div(e), o = tbase + lo * TNp + (e - lo * gch);
+        float v = colp[gi * gch + (e - lo * gch)];
+        for (int k = 0; k < KS; ++k) v += red[k * TM * TNp + o];
+        red[o] = v;
+        sum += v;
+      }
+      const float mean = team_sum(sum, ts) / (float)cnt;
+      float sq = 0.f;
+#pragma unroll 4
+      for (int e = tl; e < cnt; e += ts) {
+        int lo = dG.div(e), o = tbase + lo * TNp + (e - lo * gch);
+        float d = red[o] - mean;
+        sq += d * d;
+      }
+      const float rstd = 1.f / sqrtf(team_sum(sq, ts) / (float)cnt + GN_EPS);
+      if (tl == 0 && p.save_stats) {
+        float* o = p.save_stats + ((size_t)b * GN_GROUPS + (n0 / gch + gi)) * 2;
+        o[0] = mean;
+        o[1] = rstd;
+      }
+#pragma unroll 2
+      for (int e = tl; e < cnt; e += ts) {
+        int lo = dG.div(e), col = gi * gch + (e - lo * gch), row = s * Lout + lo;
+        float xh = (red[row * TNp + col] - mean) * rstd;
+        float ga = colp[TN + col];
+        float m, dm;
+        mish_both(xh * ga + colp[2 * TN + col], &m, &dm);
+        if (p.save_y) {
+          size_t so = ((size_t)b0 * Lout + row) * p.N + n0 + col;
+          p.save_y[so] = xh;
+          p.save_g[so] = dm * ga;
+        }
+        finish(m, s, row, col);
+      }
+    }
+  } else {
+    const int tile_elems = TM * TN;
+    for (int e = tid; e < tile_elems; e += nthr) {
+      int row = dTN.div(e), col = e - row * TN;
+      int s = dLout.div(row);
+      if (s >= S || b0 + s >= B || n0 + col >= p.N) continue;
+      float v = colp[col];
+      for (int k = 0; k < KS; ++k) v += red[(k * TM + row) * TNp + col];
+      finish(v, s, row, col);
+    }
   }
+  STAMP(9);
 }
 
 template <int MI, int NI>
@@ -443,7 +545,22 @@ static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hip
   }
   dim3 grid((p.B + tl.S - 1) / tl.S, p.Npad / (16 * tl.NI * tl.NG), nz);
   dim3 block(64 * tl.NG * tl.KS);
-  hipLaunchKernelGGL((conv_gemm_kernel<MI, NI>), grid, block, lds, st, L, tl.S, tl.NG, tl.KS);
+  ConvLaunch LL = L;
+  const int TN = 16 * tl.NI * tl.NG;
+  const int R = (p.Lout - 1) * p.stride + p.ntaps;
+  ConvAux& ax = LL.aux;
+  ax.mLout = magic_of(p.Lout);
+  ax.mTN = magic_of(TN);
+  ax.mR = magic_of(R);
+  ax.mLin = magic_of(p.Lin);
+  ax.mGch = magic_of(p.gn ? p.gch : 1);
+  ax.mPGch = magic_of(p.pro ? p.pro_gch : 1);
+  ax.mGpt = magic_of(p.gn ? TN / p.gch : 1);
+  ax.mOs = magic_of(p.osplit > 0 ? p.osplit : 1);
+  ax.mC4 = magic_of(p.Cin_p >> 2);
+  ax.mC4b = magic_of(p.x2 ? (p.Cin2_p >> 2) : 1);
+  ax.mNth16 = 0;
+  hipLaunchKernelGGL((conv_gemm_kernel<MI, NI>), grid, block, lds, st, LL, tl.S, tl.NG, tl.KS);
   return hipGetLastError();
 }
 

@@ -94,10 +94,10 @@ struct Op {
   GnW gnw;
   const float* tbias = nullptr;
   BufRef src, src2, dst, res;
-  int save_y = NONE, save_st = NONE;
+  int save_y = NONE, save_g = NONE, save_st = NONE;
   bool pro = false;
   GnW pro_gn;
-  int pro_y = NONE, pro_st = NONE;
+  int pro_y = NONE, pro_g = NONE, pro_st = NONE;
   double flops = 0;        // algorithmic (zero-padding taps excluded), per candidate
   // head
   int v_buf = NONE, dv_buf = NONE;
@@ -111,6 +111,7 @@ struct Binding {
   float* grad = nullptr;
   int ldg = 0;
   const long long* t = nullptr;
+  int t_uniform = -1;
   float* ws = nullptr;
   float* y = nullptr;      // head output
 };
@@ -601,12 +602,12 @@ struct Builder {
     std::string prefix;
     int cin, cout, L;
     bool has_res;
-    int y0, st0, y1, st1;
+    int y0, st0, y1, st1, g0, g1;
     GnW gn0, gn1;
   };
 
   RBRec res_block(const std::string& p, BufRef src, int cin, int cout, int L, BufRef dst, bool save) {
-    RBRec rec{p, cin, cout, L, cin != cout, NONE, NONE, NONE, NONE, {}, {}};
+    RBRec rec{p, cin, cout, L, cin != cout, NONE, NONE, NONE, NONE, NONE, NONE, {}, {}};
     std::string b0 = p + ".blocks.0.block", b1 = p + ".blocks.1.block";
     Op o0 = conv_fwd(b0 + ".0", cin, cout, 5, 1, 2, L, nullptr, 0);
     o0.gn = true;
@@ -625,8 +626,10 @@ struct Builder {
     if (save) {
       o0.save_y = rec.y0 = net->new_buf((size_t)L * cout);
       o0.save_st = rec.st0 = net->new_buf(2 * GN_GROUPS);
+      o0.save_g = rec.g0 = net->new_buf((size_t)L * cout);
       o1.save_y = rec.y1 = net->new_buf((size_t)L * cout);
       o1.save_st = rec.st1 = net->new_buf(2 * GN_GROUPS);
+      o1.save_g = rec.g1 = net->new_buf((size_t)L * cout);
     }
     net->fwd.push_back(o0);
     net->fwd.push_back(o1);
@@ -641,6 +644,7 @@ struct Builder {
     kb.pro = true;
     kb.pro_gn = r.gn1;
     kb.pro_y = r.y1;
+    kb.pro_g = r.g1;
     kb.pro_st = r.st1;
     int da0 = net->new_buf((size_t)r.L * r.cout);
     kb.dst = {da0, r.cout, 0};
@@ -650,6 +654,7 @@ struct Builder {
     kc.pro = true;
     kc.pro_gn = r.gn0;
     kc.pro_y = r.y0;
+    kc.pro_g = r.g0;
     kc.pro_st = r.st0;
     if (r.has_res) kc.src2 = g; else kc.res = g;
     kc.dst = dst;
@@ -912,12 +917,11 @@ struct Resolver {
     p.osplit = op.osplit;
     p.gn = op.gn ? 1 : 0; p.gch = op.gn ? op.gnw.gch : 1;
     p.gamma = op.gnw.gamma; p.beta = op.gnw.beta;
-    p.save_y = buf(op.save_y); p.save_stats = buf(op.save_st);
-    p.tbias = op.tbias; p.t = b.t; p.T = net->T;
+    p.save_y = buf(op.save_y); p.save_g = buf(op.save_g); p.save_stats = buf(op.save_st);
+    p.tbias = op.tbias; p.t = b.t; p.t_uniform = b.t_uniform; p.T = net->T;
     p.res = ptr(op.res, &p.ldres);
     p.pro = op.pro ? 1 : 0; p.pro_gch = op.pro ? op.pro_gn.gch : 1;
-    p.pro_y = buf(op.pro_y); p.pro_stats = buf(op.pro_st);
-    p.pro_gamma = op.pro_gn.gamma; p.pro_beta = op.pro_gn.beta;
+    p.pro_y = buf(op.pro_y); p.pro_g = buf(op.pro_g); p.pro_stats = buf(op.pro_st);
     p.B = B;
     return p;
   }
@@ -953,6 +957,10 @@ int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, 
   int nz = n1 ? 2 : 1;
   for (size_t i = 0; i < ops.size(); ++i) {
     const Op& op = ops[i];
+#ifdef TREBI_STAMPS
+    if (const char* lim = getenv("TREBI_STOP_AFTER"))
+      if ((int)i > atoi(lim)) break;
+#endif
     if (op.kind == 1) {
       HeadLaunch L{};
       L.p[0] = r0.head(op, want_grad);
@@ -1319,7 +1327,7 @@ static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const
       if (!(dead && d.skip_dead_evals)) {
         for (int k = 0; k < d.n_guide_steps; ++k) {
           Binding br, bc;
-          br.x = x; br.ldx = D; br.grad = s->rgrad; br.ldg = D; br.t = t; br.ws = s->ws_r; br.y = values;
+          br.x = x; br.ldx = D; br.grad = s->rgrad; br.ldg = D; br.t = t; br.t_uniform = i; br.ws = s->ws_r; br.y = values;
           bc = br; bc.grad = s->cgrad; bc.ws = s->ws_c; bc.y = costs;
           const bool grad = !stopped;
           if (s->cost && s->dual) {
@@ -1336,7 +1344,7 @@ static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const
       }
     }
     Binding bu;
-    bu.x = x; bu.ldx = D; bu.out = s->x0; bu.ldo = D; bu.t = t; bu.ws = s->ws_u;
+    bu.x = x; bu.ldx = D; bu.out = s->x0; bu.ldo = D; bu.t = t; bu.t_uniform = i; bu.ws = s->ws_u;
     if (int e = run_ops(s->unet->fwd, s->unet, bu, nullptr, nullptr, nullptr, B, false, st, prof)) return e;
     float* ch = chain ? chain + (size_t)(T - i) * per : nullptr;
     HIPCHK(launch_ddpm_update(sp, x, s->x0, noise + (size_t)(T - i) * per, t, s->plv, s->c1, s->c2, B, ch, st));

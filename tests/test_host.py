@@ -1,0 +1,66 @@
+"""CPU suite: host-side logic -- module parameter trees, schedule buffers, sharding arithmetic, and that
+the product path refuses to run without a GPU (no CPU fallback)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _common import GOLDEN
+from trebi_amd import spec
+from trebi_amd.parallel import shard_bounds
+
+
+def test_module_state_dict_keys_and_shapes():
+    from diffuser.models import TemporalUnet, ValueFunction
+    for cls, fn, args in ((TemporalUnet, spec.unet_param_shapes, (32, 23)), (ValueFunction, spec.value_param_shapes, (32, 23)),
+                          (TemporalUnet, spec.unet_param_shapes, (32, 23, 32, (1, 4, 8)))):
+        shapes = fn(*args)
+        net = cls(args[0], args[1], 0, **(dict(dim=args[2], dim_mults=args[3]) if len(args) > 2 else {}))
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(shapes.keys())
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(shapes[k]), k
+    # the documented examples of SURVEY.md section 8b
+    sd = TemporalUnet(32, 23, 0).state_dict()
+    assert tuple(sd['downs.0.0.blocks.0.block.0.weight'].shape) == (32, 23, 5)
+    assert tuple(sd['downs.0.3.conv.weight'].shape) == (32, 32, 3)
+    assert tuple(sd['ups.0.3.conv.weight'].shape) == (128, 128, 4)
+    assert tuple(sd['final_conv.1.weight'].shape) == (23, 32, 1)
+    assert tuple(ValueFunction(32, 23, 0).state_dict()['final_block.0.weight'].shape) == (32, 96)
+
+
+def test_value_plan_flags_the_reference_shape_bug():
+    """(1,4,8) value nets are only self-consistent at horizon 4."""
+    assert spec.value_plan(32, 23, 32, (1, 2, 4, 8))['consistent']
+    assert spec.value_plan(4, 23, 32, (1, 4, 8))['consistent']
+    assert not spec.value_plan(32, 23, 32, (1, 4, 8))['consistent']
+
+
+def test_diffusion_buffers_match_reference_schedule():
+    from diffuser.models import TemporalUnet, GaussianDiffusion
+    d = GaussianDiffusion(TemporalUnet(32, 23, 0), 32, 17, 6, n_timesteps=20, loss_type='l2', clip_denoised=False,
+                          predict_epsilon=False)
+    ref = np.load(os.path.join(GOLDEN, 'schedule_T20.npz'))
+    for k in ref.files:
+        np.testing.assert_array_equal(getattr(d, k).numpy(), ref[k], err_msg=k)      # bit-exact tables
+    keys = [k for k in d.state_dict() if not k.startswith('model.')]
+    assert 'loss_fn.weights' in keys and 'posterior_mean_coef2' in keys
+    assert d.model.max_timesteps == 20
+
+
+def test_no_cpu_fallback():
+    from diffuser.models import TemporalUnet
+    net = TemporalUnet(32, 23, 0)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        net(torch.zeros(2, 32, 23), None, torch.zeros(2, dtype=torch.long))
+
+
+def test_shard_bounds_partition():
+    for n in (1, 7, 64, 65, 4096, 65536):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, w, r) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
