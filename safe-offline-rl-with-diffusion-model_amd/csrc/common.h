@@ -53,15 +53,22 @@ struct ConvP {
   int B;
 };
 
-// Magic multipliers for the index divisions the kernel does (n / d == umulhi(n, m) for n*d < 2^32),
-// computed once on the host so no workgroup spends instructions on integer division.
-struct ConvAux {
-  unsigned mLout, mTN, mR, mLin, mGch, mPGch, mGpt, mOs, mC4, mC4b, mNth16;
+// Everything about one launch that does not depend on the net (tile geometry, the LDS carve, loop
+// bounds and the magic multipliers n / d == umulhi(n, m), m = ceil(2^32/d), m == 0 for d == 1), computed
+// once on the host so that no workgroup spends instructions on derived integers or divisions.
+struct ConvGeo {
+  int S, NG, KS, TM, TN, TNp;
+  int R, ldA, ld2, li_min, cbpt, KK1, KK, chunk;
+  // LDS carve, float offsets:  [slab | slab2 | yslab] aliased by [red | red2] ; res | colp | tbrow | pstat
+  int oSlab2, oY, red1, oRes, oColp, oTb, oPstat, total;
+  int c4n, c4n2, nSlab4, nX24, nY4;               // float4 counts of the staged streams
+  int gpt, cnt, pcnt, ts_epi, ts_pro;             // GroupNorm teams
+  unsigned mLout, mTN, mR, mLin, mGch, mPGch, mGpt, mOs, mC4, mC4b, mNG, mCbpt;
 };
 
 struct ConvLaunch {
   ConvP p[2];                      // blockIdx.z selects (reward / cost net run in one launch)
-  ConvAux aux;                     // both nets of a launch have identical shapes
+  ConvGeo g;                       // both nets of a launch have identical shapes
 };
 
 struct Tile {
