@@ -57,18 +57,31 @@ struct ConvP {
 // bounds and the magic multipliers n / d == umulhi(n, m), m = ceil(2^32/d), m == 0 for d == 1), computed
 // once on the host so that no workgroup spends instructions on derived integers or divisions.
 struct ConvGeo {
-  int S, NG, KS, TM, TN, TNp;
-  int R, ldA, ld2, li_min, cbpt, KK1, KK, chunk;
+  int S, NG, KS, nthr;                            // nthr = 64*NG*KS threads work in this stage
+  int TM, TN, TNp;
+  int R, ldA, ld2, cbpt, KK1, KK, chunk;
+  int nv, vlo, fh, hr;                            // valid input rows [vlo, vlo+nv) per candidate, front / total halo rows
   // LDS carve, float offsets:  [slab | slab2 | yslab] aliased by [red | red2] ; res | colp | tbrow | pstat
   int oSlab2, oY, red1, oRes, oColp, oTb, oPstat, total;
-  int c4n, c4n2, nSlab4, nX24, nY4;               // float4 counts of the staged streams
-  int gpt, cnt, pcnt, ts_epi, ts_pro;             // GroupNorm teams
-  unsigned mLout, mTN, mR, mLin, mGch, mPGch, mGpt, mOs, mC4, mC4b, mNG, mCbpt;
+  int c4n, c4n2, nValid4, nHalo4, nX24, nRes4, tn4;   // float4 counts of the staged streams
+  int gpt, cnt4, pcnt4, gch4, pgch4, ts_epi, ts_pro;  // GroupNorm teams (float4 granularity)
+  int veco, vecr;                                 // output / identity residual are float4-addressable
+  unsigned mLout, mTN4, mNv, mHr, mGch4, mPGch4, mGpt, mOs, mC4, mC4b, mNG, mCbpt, mTN;
 };
 
 struct ConvLaunch {
   ConvP p[2];                      // blockIdx.z selects (reward / cost net run in one launch)
   ConvGeo g;                       // both nets of a launch have identical shapes
+};
+
+// One stage of a chained launch: consecutive layers whose workgroups only depend on their own
+// candidates' previous outputs (all output columns in one workgroup) run in ONE launch, separated by
+// a workgroup barrier instead of a kernel boundary.  The table lives in device memory.
+struct ChainStage {
+  ConvP p[2];
+  ConvGeo g;
+  int variant;                     // 0: <1,1,vec> 1: <2,1,vec> 2: <1,1,novec> 3: <2,1,novec> 4: <1,2,vec> 5: <4,1,vec> 6: <2,2,vec>
+  int pad_[3];
 };
 
 struct Tile {
@@ -80,6 +93,11 @@ struct Tile {
 size_t conv_lds_bytes(const ConvP& p, const Tile& tl);
 hipError_t conv_init_device();
 hipError_t launch_conv(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st);
+ConvGeo conv_make_geo(const ConvP& p, const Tile& tl);
+bool conv_vec_ok(const ConvP& p);
+int conv_chain_variant(const Tile& tl, bool vec);      // -1 if the tile shape has no chain variant
+hipError_t launch_conv_chain(const ChainStage* dev_stages, int nstages, int nz, int nblocks, size_t lds_bytes,
+                             int t_uniform, const long long* t, hipStream_t st);
 
 // Value head (temporal.py:237-238) forward + the seed of the backward.
 struct HeadP {

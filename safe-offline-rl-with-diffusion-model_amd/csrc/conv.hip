@@ -1,0 +1,672 @@
+// conv.hip -- the implicit-GEMM convolution of the TREBI hot path on gfx950 (CDNA4).
+//
+// Every Conv1d / ConvTranspose1d / input-gradient convolution of TemporalUnet and ValueFunction
+// (reference: diffuser/models/temporal.py:18-46, helpers.py:30-63) is one `conv_body`:
+//
+//   M = (candidate, position) rows, N = output channels, K = (tap, input channel), on
+//   v_mfma_f32_16x16x4_f32 (exact float32: bit for bit an fmaf chain).
+//   A workgroup owns S whole candidates x TN columns (TN a multiple of the GroupNorm group):
+//     1. every wave preloads the packed weights of its K-chunk from L2 into registers,
+//     2. the candidates' activations are staged once into LDS (zero halo), all loads of a thread
+//        issued before its first LDS write -- one memory round trip per layer,
+//     3. backward only: GroupNorm backward of the producing block in LDS (the staged gradient was
+//        already multiplied by the saved mish'(z)*gamma on the way in),
+//     4. K loop: one ds_read_b128 + 4 MFMA per 16 channels per 16x16 tile,
+//     5. split-K partials through LDS, then per (candidate, group) teams of 16/64 lanes: reduce,
+//        bias, GroupNorm statistics (two passes, DPP reductions), normalise, Mish (one exp), time
+//        bias, 1x1 / identity residual, float4 stores.
+//
+// The kernel is latency/issue-bound at planning batch sizes (64 candidates), so the code is written
+// for a short instruction stream: all derived integers and division multipliers come from the host
+// (ConvGeo), kernel-argument fields are read once and pinned in scalar registers, everything moves
+// in float4, and layers whose workgroups are independent are chained inside one launch
+// (conv_chain_kernel) with a workgroup barrier instead of a kernel boundary.
+#include "device_util.h"
+
+namespace trebi {
+
+#ifdef TREBI_STAMPS
+__device__ unsigned long long g_stamps[32];
+extern "C" int trebi_debug_read_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#endif
+
+// n / d with a host-computed multiplier (ConvGeo): one mul-hi.
+struct FastDiv {
+  unsigned d, m;
+  __device__ FastDiv(unsigned dd, unsigned mm) : d(dd), m(mm) {}
+  __device__ __forceinline__ unsigned div(unsigned n) const { return m == 0 ? n : __umulhi(n, m); }
+};
+static inline unsigned magic_of(unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
+
+bool conv_vec_ok(const ConvP& q) {
+  bool v = ((q.ldx & 3) == 0) && ((q.Cin & 3) == 0) && ((((uintptr_t)q.x) & 15) == 0);
+  if (q.x2) v = v && ((q.ldx2 & 3) == 0) && ((q.Cin2 & 3) == 0) && ((((uintptr_t)q.x2) & 15) == 0);
+  return v;
+}
+
+ConvGeo conv_make_geo(const ConvP& p, const Tile& tl) {
+  ConvGeo g{};
+  g.S = tl.S; g.NG = tl.NG; g.KS = tl.KS; g.nthr = 64 * tl.NG * tl.KS;
+  g.TM = 16 * tl.MI; g.TN = 16 * tl.NI * tl.NG; g.TNp = g.TN + 4;
+  g.R = (p.Lout - 1) * p.stride + p.ntaps;
+  g.ldA = p.Cin_p + 4;
+  g.ld2 = p.x2 ? p.Cin2_p + 4 : 0;
+  const int li_min = p.tap_lo - p.pad;
+  g.vlo = li_min > 0 ? li_min : 0;
+  int vhi = li_min + g.R < p.Lin ? li_min + g.R : p.Lin;
+  g.nv = vhi - g.vlo;
+  g.fh = g.vlo - li_min;
+  g.hr = g.R - g.nv;
+  g.cbpt = p.Cin_p >> 4;
+  g.KK1 = p.ntaps * g.cbpt;
+  g.KK = g.KK1 + (p.x2 ? (p.Cin2_p >> 4) : 0);
+  g.chunk = (g.KK + g.KS - 1) / g.KS;
+  int nA = g.S * g.R * g.ldA, n2 = p.x2 ? g.S * p.Lout * g.ld2 : 0, nY = p.pro ? g.S * p.Lin * g.ldA : 0;
+  g.oSlab2 = nA;
+  g.oY = nA + n2;
+  g.red1 = g.KS * g.TM * g.TNp;
+  int red = g.red1 * (p.x2 ? 2 : 1), stage = nA + n2 + nY;
+  int body = ((stage > red ? stage : red) + 3) & ~3;
+  g.oRes = body;
+  g.oColp = g.oRes + (p.res ? g.TM * g.TNp : 0);
+  g.oTb = g.oColp + 4 * g.TN;
+  g.oPstat = g.oTb + (p.tbias ? g.S * g.TN : 0);
+  g.total = g.oPstat + (p.pro ? 2 * g.S * GN_GROUPS : 0);
+  g.c4n = p.Cin_p >> 2;
+  g.c4n2 = p.x2 ? (p.Cin2_p >> 2) : 1;
+  g.nValid4 = g.S * g.nv * g.c4n;
+  g.nHalo4 = g.S * g.hr * g.c4n;
+  g.nX24 = p.x2 ? g.S * p.Lout * g.c4n2 : 0;
+  g.tn4 = g.TN / 4;
+  g.nRes4 = g.TM * g.tn4;
+  const int nteams16 = 4 * tl.NG * tl.KS;
+  g.gpt = p.gn ? g.TN / p.gch : 1;
+  g.gch4 = p.gn ? p.gch / 4 : 1;
+  g.pgch4 = p.pro ? p.pro_gch / 4 : 1;
+  g.cnt4 = p.gn ? p.Lout * g.gch4 : 1;
+  g.pcnt4 = p.pro ? p.Lin * g.pgch4 : 1;
+  g.ts_epi = (g.S * g.gpt * 4 <= nteams16) ? 64 : 16;
+  g.ts_pro = (g.S * GN_GROUPS * 4 <= nteams16) ? 64 : 16;
+  const int ophase = p.osplit > 0 ? 2 : 1;
+  (void)ophase;
+  g.veco = ((p.ldo & 3) == 0) && ((p.N & 3) == 0) && ((((uintptr_t)p.out) & 15) == 0) &&
+           (p.osplit <= 0 || (p.osplit & 3) == 0);
+  g.vecr = p.res ? (((p.ldres & 3) == 0) && ((p.N & 3) == 0) && ((((uintptr_t)p.res) & 15) == 0)) : 0;
+  g.mLout = magic_of(p.Lout); g.mTN4 = magic_of(g.tn4); g.mNv = magic_of(g.nv > 0 ? g.nv : 1);
+  g.mHr = magic_of(g.hr > 0 ? g.hr : 1); g.mGch4 = magic_of(g.gch4); g.mPGch4 = magic_of(g.pgch4);
+  g.mGpt = magic_of(g.gpt); g.mOs = magic_of(p.osplit > 0 ? p.osplit : 1); g.mC4 = magic_of(g.c4n);
+  g.mC4b = magic_of(g.c4n2); g.mNG = magic_of(g.NG); g.mCbpt = magic_of(g.cbpt); g.mTN = magic_of(g.TN);
+  return g;
+}
+
+size_t conv_lds_bytes(const ConvP& p, const Tile& tl) {
+  return (size_t)conv_make_geo(p, tl).total * sizeof(float);
+}
+
+// Keep a wave-uniform value in scalar registers: without this the compiler re-reads kernel-argument
+// fields with an s_load + s_waitcnt in front of every use (hundreds of stall cycles per use).
+#define PIN(x) asm volatile("" : "+s"(x))
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// Sum over a team of 16 lanes (one DPP row) or the whole wave, result in every lane; VALU only.
+__device__ __forceinline__ float team_sum(float v, int ts) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);     // row_half_mirror
+  v += dpp_f<0x140>(v);     // row_mirror
+  if (ts == 64) {           // wave-uniform: the whole wave is one team, every lane is active
+    const int iv = __float_as_int(v);
+    v = __int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16)) +
+        __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  }
+  return v;
+}
+__device__ __forceinline__ float hsum(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
+
+// float4 (VEC) or 4 guarded scalars from a row with `left` valid floats starting at sp
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const float* sp, int left) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (VEC) {
+    if (left > 0) v = *(const f32x4*)sp;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < left) v[e] = sp[e];
+  }
+  return v;
+}
+
+// WB = reduction steps whose weights a wave preloads into registers before anything else.
+template <int MI, int NI, bool VEC>
+__device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, float* smem, const int b0, const int n0,
+                                          const int tid, int t_uniform, const long long* tptr) {
+  constexpr int WB = (NI == 1) ? (MI <= 2 ? 24 : 16) : 8;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- every argument field used below, read once and pinned in scalar registers ----------------
+  const float* px = p.x;  const float* pw = p.w;  float* pout = p.out;
+  int ldx = p.ldx, Cin = p.Cin, Lin = p.Lin, Lout = p.Lout, stride = p.stride, B = p.B, N = p.N, Npad = p.Npad;
+  int S = G.S, NG = G.NG, KS = G.KS, nthr = G.nthr, TM = G.TM, TN = G.TN, TNp = G.TNp, R = G.R, ldA = G.ldA,
+      ld2 = G.ld2;
+  int cbpt = G.cbpt, KK1 = G.KK1, KK = G.KK, chunk = G.chunk, nv = G.nv, fh = G.fh;
+  PIN(px); PIN(pw); PIN(pout); PIN(ldx); PIN(Cin); PIN(Lin); PIN(Lout); PIN(stride); PIN(B); PIN(N); PIN(Npad);
+  PIN(S); PIN(NG); PIN(KS); PIN(nthr); PIN(TM); PIN(TN); PIN(TNp); PIN(R); PIN(ldA); PIN(ld2);
+  PIN(cbpt); PIN(KK1); PIN(KK); PIN(chunk); PIN(nv); PIN(fh);
+  const bool has2 = p.x2 != nullptr, haspro = p.pro != 0, hasres = p.res != nullptr, hastb = p.tbias != nullptr,
+             hasgn = p.gn != 0;
+  const bool active = tid < nthr;
+  float* slab = smem;
+  float* slab2 = smem + G.oSlab2;
+  float* yslab = smem + G.oY;
+  float* restile = smem + G.oRes;
+  float* colp = smem + G.oColp;          // [4][TN]: bias, gamma, beta, bias2
+  float* tbrow = smem + G.oTb;           // [S][TN]
+  float* pstat = smem + G.oPstat;        // [S*8][2] mean, rstd of the producing block
+  const FastDiv dLout(Lout, G.mLout), dTN4(G.tn4, G.mTN4), dTN(TN, G.mTN);
+  const int nvs = (B - b0 < S) ? B - b0 : S;       // candidates of this tile that exist
+  STAMP(0);
+
+  // ---- wave geometry + weight preload (registers) -------------------------------------------
+  // v_mfma_f32_16x16x4_f32: lane l feeds A[row l&15][k l>>4] and B[k l>>4][col l&15].  The
+  // reduction index is permuted so that lane-group g = l>>4 owns channels 16*kk+4g .. +3 of
+  // step kk and the four MFMAs of the step consume one float4 of A (LDS) and one of B (global).
+  const int g = lane >> 4, lr = lane & 15;
+  const int ks = FastDiv(NG, G.mNG).div(wave), ng = wave - ks * NG;
+  const int k_begin = active ? ks * chunk : 0;
+  const int k_end = active ? ((k_begin + chunk < KK) ? k_begin + chunk : KK) : 0;
+  // uniform base (scalar registers) + one 32-bit per-lane offset: the loads need no per-lane 64-bit math
+  const unsigned wlane = (unsigned)((g * Npad + n0 + ng * NI * 16 + lr) * 4);
+  const unsigned wstep = (unsigned)Npad * 16u;     // floats per kk step
+  f32x4 wreg[WB][NI];
+  {
+    const float* wu = pw + (size_t)k_begin * wstep;
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+      if (k_begin + u < k_end) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wu + wlane + ni * 64);
+      }
+      wu += wstep;
+    }
+  }
+  STAMP(1);
+
+  // ---- stage everything this workgroup reads from global: all loads first, then the LDS writes ----
+  if (active) {
+    float c0 = 0.f, c1 = 1.f, c2 = 0.f, c3 = 0.f;
+    const bool colt = tid < TN;
+    if (colt) {
+      int n = n0 + tid;
+      bool ok = n < N;
+      if (ok && p.bias) c0 = p.bias[n];
+      if (ok && hasgn) { c1 = p.gamma[n]; c2 = p.beta[n]; }
+      if (ok && p.bias2) c3 = p.bias2[n];
+    }
+    auto tb_load = [&](int e) -> float {
+      int s = dTN.div(e), c = e - s * TN;
+      int n = n0 + c;
+      if (s >= nvs || n >= N) return 0.f;
+      long long tt = t_uniform >= 0 ? t_uniform : tptr[b0 + s];
+      tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
+      return p.tbias[(unsigned)tt * (unsigned)N + n];
+    };
+    auto ps_load = [&](int i) -> float {
+      return (i < nvs * GN_GROUPS * 2) ? p.pro_stats[(unsigned)b0 * GN_GROUPS * 2 + i] : 0.f;
+    };
+    float tbv[2] = {0.f, 0.f}, psv = 0.f;
+    if (hastb) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < S * TN) tbv[u] = tb_load(tid + u * nthr);
+    }
+    if (haspro && tid < S * GN_GROUPS * 2) psv = ps_load(tid);
+    // identity residual tile
+    f32x4 rv[2];
+    int ro[2] = {-1, -1};
+    const int nRes4 = G.nRes4;
+    auto res_item = [&](int e, int* o) -> f32x4 {
+      int row = dTN4.div(e), c4 = e - row * G.tn4;
+      *o = row * TNp + 4 * c4;
+      int left = N - n0 - 4 * c4;
+      if (row >= nvs * Lout) left = 0;
+      const float* sp = p.res + ((unsigned)b0 * Lout + row) * (unsigned)p.ldres + n0 + 4 * c4;
+      return G.vecr ? load4<true>(sp, left) : load4<false>(sp, left);
+    };
+    if (hasres) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < nRes4) rv[u] = res_item(tid + u * nthr, &ro[u]);
+    }
+    // primary source: the valid rows of the S candidates (the halo is zero-filled separately).  With a
+    // prologue the source is dL/d(Mish output); it is multiplied by the saved mish'(z)*gamma on the way
+    // in (the slab then holds dL/dxhat) and the saved xhat goes to yslab with the same indexing.
+    {
+      const FastDiv dC4(G.c4n, G.mC4), dNv(nv, G.mNv);
+      const int c4n = G.c4n, total = G.nValid4, vlo = G.vlo;
+      const float* pg = p.pro_g;
+      const float* py = p.pro_y;
+      for (int base = tid; base < total; base += 4 * nthr) {
+        f32x4 v[4], m[4], y[4];
+        int so[4], yo[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int idx = base + u * nthr;
+          so[u] = -1;
+          if (idx < total) {
+            int rowv = dC4.div(idx), c4 = idx - rowv * c4n;
+            int s = dNv.div(rowv), i = rowv - s * nv;
+            so[u] = (s * R + fh + i) * ldA + 4 * c4;
+            yo[u] = (s * Lin + i) * ldA + 4 * c4;
+            unsigned grow = (unsigned)(b0 + s) * Lin + vlo + i;
+            int left = s < nvs ? Cin - 4 * c4 : 0;
+            v[u] = load4<VEC>(px + grow * (unsigned)ldx + 4 * c4, left);
+            if (haspro) {
+              m[u] = load4<true>(pg + grow * (unsigned)Cin + 4 * c4, left);
+              y[u] = load4<true>(py + grow * (unsigned)Cin + 4 * c4, left);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (so[u] >= 0) {
+            if (haspro) {
+              *(f32x4*)&slab[so[u]] = v[u] * m[u];
+              *(f32x4*)&yslab[yo[u]] = y[u];
+            } else {
+              *(f32x4*)&slab[so[u]] = v[u];
+            }
+          }
+      }
+      const FastDiv dHr(G.hr, G.mHr);
+      const int nh = G.nHalo4, hr = G.hr;
+      for (int idx = tid; idx < nh; idx += nthr) {
+        int h = dC4.div(idx), c4 = idx - h * c4n;
+        int s = dHr.div(h), k = h - s * hr;
+        int j = k < fh ? k : k + nv;
+        *(f32x4*)&slab[(s * R + j) * ldA + 4 * c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (has2) {           // second source rows at the output positions -> slab2
+      const FastDiv dC4(G.c4n2, G.mC4b);
+      const int c4n = G.c4n2, total = G.nX24, C2 = p.Cin2;
+      const float* p2 = p.x2;
+      const unsigned ldx2 = p.ldx2;
+      for (int base = tid; base < total; base += 2 * nthr) {
+        f32x4 v[2];
+        int so[2] = {-1, -1};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          int idx = base + u * nthr;
+          if (idx < total) {
+            int row = dC4.div(idx), c4 = idx - row * c4n;
+            so[u] = row * ld2 + 4 * c4;
+            int left = row < nvs * Lout ? C2 - 4 * c4 : 0;
+            v[u] = load4<VEC>(p2 + ((unsigned)b0 * Lout + row) * ldx2 + 4 * c4, left);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (so[u] >= 0) *(f32x4*)&slab2[so[u]] = v[u];
+      }
+    }
+    if (haspro) {
+      if (tid < S * GN_GROUPS * 2) pstat[tid] = psv;
+      for (int i = tid + nthr; i < S * GN_GROUPS * 2; i += nthr) pstat[i] = ps_load(i);
+    }
+    if (colt) {
+      colp[tid] = c0;
+      colp[TN + tid] = c1;
+      colp[2 * TN + tid] = c2;
+      colp[3 * TN + tid] = c3;
+    }
+    if (hastb) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < S * TN) tbrow[tid + u * nthr] = tbv[u];
+      for (int e = tid + 2 * nthr; e < S * TN; e += nthr) tbrow[e] = tb_load(e);
+    }
+    if (hasres) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (ro[u] >= 0) *(f32x4*)&restile[ro[u]] = rv[u];
+      for (int e = tid + 2 * nthr; e < nRes4; e += nthr) {
+        int o;
+        f32x4 v = res_item(e, &o);
+        *(f32x4*)&restile[o] = v;
+      }
+    }
+  }
+  STAMP(2);
+  __syncthreads();
+  STAMP(3);
+
+  // Teams of 16 (or 64) lanes each own one (candidate, GroupNorm group): all passes over a group stay
+  // inside the team (DPP reductions), so neither the prologue nor the epilogue needs a barrier between
+  // its passes.  Every team works on float4s (groups are multiples of 4 channels).
+
+  // ---- prologue: GroupNorm backward of the producing Conv1dBlock, in LDS ----------------------
+  //   slab = dxhat = dA * mish'(z) * gamma (multiplied while staging), yslab = xhat (saved by the forward)
+  //   dY = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat * xhat))
+  if (haspro) {
+    if (active) {
+      const int gch = p.pro_gch, cnt4 = G.pcnt4, pg4 = G.pgch4, ninst = S * GN_GROUPS;
+      const int ts = G.ts_pro;
+      const int team = ts == 64 ? (tid >> 6) : (tid >> 4), tl = tid & (ts - 1),
+                nteams = ts == 64 ? (nthr >> 6) : (nthr >> 4);
+      const FastDiv dG(pg4, G.mPGch4);
+      const float icnt = 1.f / (float)(cnt4 * 4);
+      for (int inst = team; inst < ninst; inst += nteams) {
+        int s = inst >> 3, gi = inst & 7;
+        if (s >= nvs) continue;
+        const float rstd = pstat[2 * inst + 1];
+        const int ybase = s * Lin * ldA + gi * gch, dbase = (s * R + fh) * ldA + gi * gch;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 2
+        for (int e = tl; e < cnt4; e += ts) {
+          int li = dG.div(e), o = li * ldA + 4 * (e - li * pg4);
+          f32x4 d = *(const f32x4*)&slab[dbase + o];
+          f32x4 x = *(const f32x4*)&yslab[ybase + o];
+          s1 += hsum(d);
+          s2 += hsum(d * x);
+        }
+        const float m1 = team_sum(s1, ts) * icnt, m2 = team_sum(s2, ts) * icnt;
+#pragma unroll 2
+        for (int e = tl; e < cnt4; e += ts) {
+          int li = dG.div(e), o = li * ldA + 4 * (e - li * pg4);
+          f32x4 d = *(const f32x4*)&slab[dbase + o];
+          f32x4 x = *(const f32x4*)&yslab[ybase + o];
+          *(f32x4*)&slab[dbase + o] = (d - m1 - x * m2) * rstd;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  STAMP(4);
+
+  // ---- implicit GEMM on the f32 matrix cores --------------------------------------------
+  int rowA[MI], row2[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int r = mi * 16 + lr;
+    int s = dLout.div(r), lo = r - s * Lout;
+    bool ok = s < S;
+    rowA[mi] = ok ? (s * R + lo * stride) * ldA + 4 * g : 4 * g;
+    row2[mi] = ok ? (s * Lout + lo) * ld2 + 4 * g : 4 * g;
+  }
+  f32x4 acc[MI][NI], acc2[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  const FastDiv dCb(cbpt, G.mCbpt);
+  for (int base = k_begin; base < k_end; base += WB) {
+    if (base != k_begin) {                      // later blocks (large reductions only): reload the registers
+      const float* wu = pw + (size_t)base * wstep;
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        if (base + u < k_end) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wu + wlane + ni * 64);
+        }
+        wu += wstep;
+      }
+    }
+    int tau = dCb.div(base), cb = base - tau * cbpt;
+    int aoff = tau * ldA + cb * 16;
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+      const int kk = base + u;
+      if (kk < k_end) {
+        f32x4 a[MI];
+        if (kk < KK1) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc[mi][ni], 0, 0, 0);
+          aoff += 16;
+          if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
+        } else {
+          const int a2 = (kk - KK1) * 16;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab2[row2[mi] + a2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc2[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc2[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  }
+  STAMP(5);
+  __syncthreads();     // every wave is done with the staged activations; LDS becomes the reduce buffer
+
+  // ---- split-K partials -> LDS.  C/D layout: col = lane&15, row = 4*(lane>>4) + reg -------
+  float* red = smem;
+  float* red2 = smem + G.red1;
+  const int kstride = TM * TNp;
+  if (active) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int o = ks * kstride + (mi * 16 + g * 4 + q) * TNp + (ng * NI + ni) * 16 + lr;
+          red[o] = acc[mi][ni][q];
+          if (has2) red2[o] = acc2[mi][ni][q];
+        }
+  }
+  __syncthreads();
+  STAMP(6);
+  if (!active) return;
+
+  const FastDiv dOs(p.osplit > 0 ? p.osplit : 1, G.mOs);
+  const int osplit = p.osplit;
+  const unsigned ldo = p.ldo;
+  const bool veco = G.veco != 0;
+  // finish 4 adjacent output columns: time bias, second-source sum, residual, store
+  auto finish = [&](f32x4 v, int s, int row, int col) {
+    const int o = row * TNp + col;
+    if (hastb) v += *(const f32x4*)&tbrow[s * TN + col];
+    if (has2) {
+      f32x4 v2 = *(const f32x4*)&colp[3 * TN + col];
+      for (int k = 0; k < KS; ++k) v2 += *(const f32x4*)&red2[k * kstride + o];
+      v += v2;
+    }
+    if (hasres) v += *(const f32x4*)&restile[o];
+    const int n = n0 + col;
+    unsigned orow = (unsigned)b0 * Lout + row;
+    float* dst;
+    if (osplit > 0) {
+      int ph = dOs.div(n);
+      dst = pout + (orow * 2 + ph) * ldo + (n - ph * osplit);
+    } else {
+      dst = pout + orow * ldo + n;
+    }
+    if (veco) {
+      if (n < N) *(f32x4*)dst = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < N) dst[e] = v[e];
+    }
+  };
+
+  if (hasgn) {
+    // ---- split-K reduce + bias, GroupNorm statistics (two passes), normalise, Mish: per team --------
+    const int gch = p.gch, g4 = G.gch4, cnt4 = G.cnt4, gpt = G.gpt, ninst = S * gpt;
+    const int ts = G.ts_epi;
+    const int team = ts == 64 ? (tid >> 6) : (tid >> 4), tl = tid & (ts - 1),
+              nteams = ts == 64 ? (nthr >> 6) : (nthr >> 4);
+    const FastDiv dG(g4, G.mGch4), dGpt(gpt, G.mGpt);
+    const float icnt = 1.f / (float)(cnt4 * 4);
+    float* sy = p.save_y;
+    float* sg = p.save_g;
+    for (int inst = team; inst < ninst; inst += nteams) {
+      int s = dGpt.div(inst), gi = inst - s * gpt;
+      if (s >= nvs) continue;
+      const int tbase = s * Lout * TNp + gi * gch;
+      float sum = 0.f;
+#pragma unroll 2
+      for (int e = tl; e < cnt4; e += ts) {
+        int lo = dG.div(e), c = 4 * (e - lo * g4), o = tbase + lo * TNp + c;
+        f32x4 v = *(const f32x4*)&colp[gi * gch + c];
+        for (int k = 0; k < KS; ++k) v += *(const f32x4*)&red[k * kstride + o];
+        *(f32x4*)&red[o] = v;
+        sum += hsum(v);
+      }
+      const float mean = team_sum(sum, ts) * icnt;
+      float sq = 0.f;
+#pragma unroll 2
+      for (int e = tl; e < cnt4; e += ts) {
+        int lo = dG.div(e), o = tbase + lo * TNp + 4 * (e - lo * g4);
+        f32x4 d = *(const f32x4*)&red[o] - mean;
+        sq += hsum(d * d);
+      }
+      const float rstd = 1.f / sqrtf(team_sum(sq, ts) * icnt + GN_EPS);
+      if (tl == 0 && p.save_stats) {
+        float* o = p.save_stats + ((unsigned)(b0 + s) * GN_GROUPS + (n0 / gch + gi)) * 2;
+        o[0] = mean;
+        o[1] = rstd;
+      }
+      for (int e = tl; e < cnt4; e += ts) {
+        int lo = dG.div(e), col = gi * gch + 4 * (e - lo * g4), row = s * Lout + lo;
+        f32x4 xh = (*(const f32x4*)&red[row * TNp + col] - mean) * rstd;
+        f32x4 ga = *(const f32x4*)&colp[TN + col];
+        f32x4 z = xh * ga + *(const f32x4*)&colp[2 * TN + col];
+        f32x4 m, dm;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a, b;
+          mish_both(z[q], &a, &b);
+          m[q] = a;
+          dm[q] = b;
+        }
+        if (sy) {
+          unsigned so = ((unsigned)b0 * Lout + row) * (unsigned)N + n0 + col;
+          *(f32x4*)&sy[so] = xh;
+          *(f32x4*)&sg[so] = dm * ga;
+        }
+        finish(m, s, row, col);
+      }
+    }
+  } else {
+    const int nitems = G.nRes4;            // TM * TN / 4
+    for (int e = tid; e < nitems; e += nthr) {
+      int row = dTN4.div(e), col = 4 * (e - row * G.tn4);
+      if (row >= nvs * Lout || n0 + col >= N) continue;
+      int s = dLout.div(row);
+      f32x4 v = *(const f32x4*)&colp[col];
+      for (int k = 0; k < KS; ++k) v += *(const f32x4*)&red[k * kstride + row * TNp + col];
+      finish(v, s, row, col);
+    }
+  }
+  STAMP(9);
+}
+
+template <int MI, int NI, bool VEC>
+__global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ConvP& p = L.p[blockIdx.z];
+  conv_body<MI, NI, VEC>(p, L.g, smem, blockIdx.x * L.g.S, blockIdx.y * L.g.TN, threadIdx.x, p.t_uniform, p.t);
+}
+
+// Consecutive layers whose workgroups depend only on their own candidates' earlier outputs, in one
+// launch.  Stage i+1 reads what stage i of the SAME workgroup wrote to global memory: the barrier's
+// vmcnt(0) drain makes those stores visible to the compute unit's later loads (each buffer is written
+// before it is first read within a launch, so no stale line can sit in the vector L1).
+__global__ __launch_bounds__(512) void conv_chain_kernel(const ChainStage* __restrict__ stages, int nstages,
+                                                         int t_uniform, const long long* tptr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  for (int i = 0; i < nstages; ++i) {
+    const ChainStage& st = stages[i];
+    const ConvP& p = st.p[blockIdx.z];
+    const int b0 = blockIdx.x * st.g.S;
+    switch (st.variant) {
+      case 0: conv_body<1, 1, true>(p, st.g, smem, b0, 0, threadIdx.x, t_uniform, tptr); break;
+      case 1: conv_body<2, 1, true>(p, st.g, smem, b0, 0, threadIdx.x, t_uniform, tptr); break;
+      case 2: conv_body<1, 1, false>(p, st.g, smem, b0, 0, threadIdx.x, t_uniform, tptr); break;
+      case 3: conv_body<2, 1, false>(p, st.g, smem, b0, 0, threadIdx.x, t_uniform, tptr); break;
+      default: break;
+    }
+    __syncthreads();
+  }
+}
+
+int conv_chain_variant(const Tile& tl, bool vec) {
+  if (tl.NI != 1) return -1;
+  if (tl.MI == 1) return vec ? 0 : 2;
+  if (tl.MI == 2) return vec ? 1 : 3;
+  return -1;
+}
+
+hipError_t launch_conv_chain(const ChainStage* dev_stages, int nstages, int nz, int nblocks, size_t lds_bytes,
+                             int t_uniform, const long long* t, hipStream_t st) {
+  hipLaunchKernelGGL(conv_chain_kernel, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages, nstages,
+                     t_uniform, t);
+  return hipGetLastError();
+}
+
+template <int MI, int NI>
+static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st) {
+  const ConvP& p = L.p[0];
+  ConvLaunch LL = L;
+  LL.g = conv_make_geo(p, tl);
+  size_t lds = (size_t)LL.g.total * sizeof(float);
+  dim3 grid((p.B + tl.S - 1) / tl.S, p.Npad / (16 * tl.NI * tl.NG), nz);
+  dim3 block(64 * tl.NG * tl.KS);
+  bool vec = conv_vec_ok(L.p[0]) && (nz < 2 || conv_vec_ok(L.p[1]));
+  if (vec)
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true>), grid, block, lds, st, LL);
+  else
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, false>), grid, block, lds, st, LL);
+  return hipGetLastError();
+}
+
+// Dynamic LDS above 64 KiB has to be opted into per kernel (once per device, at context creation).
+hipError_t conv_init_device() {
+  hipError_t e = hipSuccess;
+#define TREBI_ATTR(mi, ni)                                                                   \
+  if (e == hipSuccess)                                                                       \
+    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, true>,                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+  if (e == hipSuccess)                                                                       \
+    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, false>,                    \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  TREBI_ATTR(1, 1) TREBI_ATTR(2, 1) TREBI_ATTR(4, 1) TREBI_ATTR(8, 1)
+  TREBI_ATTR(1, 2) TREBI_ATTR(2, 2) TREBI_ATTR(4, 2)
+#undef TREBI_ATTR
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)conv_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  return e;
+}
+
+hipError_t launch_conv(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st) {
+#define TREBI_CASE(mi, ni) \
+  if (tl.MI == mi && tl.NI == ni) return launch_conv_t<mi, ni>(L, nz, tl, st);
+  TREBI_CASE(1, 1) TREBI_CASE(2, 1) TREBI_CASE(4, 1) TREBI_CASE(8, 1)
+  TREBI_CASE(1, 2) TREBI_CASE(2, 2) TREBI_CASE(4, 2)
+#undef TREBI_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace trebi
