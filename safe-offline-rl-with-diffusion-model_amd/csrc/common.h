@@ -80,7 +80,7 @@ struct ConvLaunch {
 struct ChainStage {
   ConvP p[2];
   ConvGeo g;
-  int variant;                     // 0: <1,1,vec> 1: <2,1,vec> 2: <1,1,novec> 3: <2,1,novec> 4: <1,2,vec> 5: <4,1,vec> 6: <2,2,vec>
+  int variant;                     // conv_body<MI,NI,VEC>: 0 <1,1,vec>  1 <2,1,vec>  2 <1,1,novec>  3 <2,1,novec>
   int pad_[3];
 };
 
@@ -140,6 +140,7 @@ hipError_t launch_ddpm_update(const StepP& s, float* x, const float* x0, const f
 hipError_t launch_init_x(const StepP& s, float* x, const float* noise0, int B, float* chain_out,
                          hipStream_t st);
 hipError_t launch_fill_t(long long* t, int B, int value, hipStream_t st);
+hipError_t launch_fill_f(float* p, int n, float value, hipStream_t st);
 hipError_t launch_feasibility(const float* ry, const float* cy, const float* thr, int n, float* out,
                               hipStream_t st);
 hipError_t launch_argsort_desc(const float* v, int n, long long* order, hipStream_t st);

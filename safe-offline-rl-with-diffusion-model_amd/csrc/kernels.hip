@@ -241,6 +241,15 @@ hipError_t launch_init_x(const StepP& s, float* x, const float* noise0, int B, f
 __global__ void fill_t_kernel(long long* t, int B, int value) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) t[i] = value;
 }
+__global__ void fill_f_kernel(float* p, int n, float value) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = value;
+}
+hipError_t launch_fill_f(float* p, int n, float value, hipStream_t st) {
+  int blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fill_f_kernel, dim3(blocks), dim3(256), 0, st, p, n, value);
+  return hipGetLastError();
+}
 hipError_t launch_fill_t(long long* t, int B, int value, hipStream_t st) {
   int blocks = (B + 255) / 256;
   if (blocks > 1024) blocks = 1024;

@@ -309,7 +309,8 @@ int check_desc(const trebi_net_desc* d) {
   if (d->n_mults < 1 || d->n_mults > 8) return fail(TREBI_BAD_ARG, "n_mults must be in 1..8");
   if (d->horizon < 1 || d->transition_dim < 1 || d->dim < 8 || d->max_timesteps < 1)
     return fail(TREBI_BAD_ARG, "horizon, transition_dim, max_timesteps must be >= 1 and dim >= 8");
-  if (d->dim % 8) return fail(TREBI_UNSUPPORTED_CONFIG, "dim must be a multiple of 8 (GroupNorm(8))");
+  if (d->dim % 32)
+    return fail(TREBI_UNSUPPORTED_CONFIG, "dim must be a multiple of 32 (GroupNorm(8) groups are processed as float4s)");
   for (int i = 0; i < d->n_mults; ++i)
     if (d->dim_mults[i] < 1) return fail(TREBI_BAD_ARG, "dim_mults must be positive");
   return 0;
@@ -848,8 +849,8 @@ Tile choose_tile(const Op& op, int B) {
   if (op.gn) {
     int l = op.gnw.gch / gcd(op.gnw.gch, 16) * 16;  // lcm(gch, 16)
     tnu = l / 16;
-    if (op.N % GN_GROUPS || op.Npad != op.N || units % tnu)
-      unsupported("GroupNorm(8) over %d channels does not tile", op.N);
+    if (op.N % GN_GROUPS || op.Npad != op.N || units % tnu || op.gnw.gch % 4)
+      unsupported("GroupNorm(8) over %d channels does not tile (channels must be a multiple of 32)", op.N);
   }
   if (op.osplit && op.osplit % (16 * tnu)) unsupported("phase split %d not a multiple of the tile", op.osplit);
   int NI = 1, NG = tnu;
@@ -995,6 +996,145 @@ int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, 
       prof->used++;
     } else {
       HIPCHK(launch_conv(L, nz, tl, st));
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// launch plans: the op list of one network pass resolved to launches for a fixed batch and fixed
+// buffers.  Runs of layers that keep all output columns in one workgroup are folded into ONE chained
+// launch (conv_chain_kernel); everything else is a single-layer launch.
+// ------------------------------------------------------------------------------------
+struct PlanStep {
+  int kind = 0;                    // 0 single conv, 1 value head, 2 chain
+  ConvLaunch L{};
+  Tile tl{};
+  HeadLaunch H{};
+  int nz = 1;
+  int chain_off = 0, chain_n = 0, nblocks = 0;
+  size_t chain_lds = 0;
+  double flops = 0;                // algorithmic, whole batch, all nets of the launch
+};
+typedef std::vector<PlanStep> Plan;
+
+int pow2ceil(int v) { int r = 1; while (r < v) r *= 2; return r; }
+
+// Tile for a chained stage: S candidates per workgroup, ALL output columns in the workgroup.
+bool chain_tile(const Op& op, int S, int max_n, Tile* out) {
+  if (op.kind != 0 || op.Npad > max_n || op.Npad / 16 > 8) return false;
+  if (op.gn && (op.Npad != op.N || op.gnw.gch % 4)) return false;
+  int MI = pow2ceil((S * op.Lout + 15) / 16);
+  if (MI > 2) return false;
+  int NG = op.Npad / 16;
+  int KK = (op.ntaps * op.Cin_p + op.Cin2_p) / 16;
+  int KS = std::max(1, std::min(8 / NG, std::max(1, KK / 4)));
+  *out = Tile{MI, 1, NG, KS, S};
+  return true;
+}
+
+int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vector<const std::vector<Op>*>& lists1,
+               const Resolver& r0, const Resolver* r1, int B, bool want_grad, int chain_S, int chain_max_n,
+               std::vector<ChainStage>& tab, Plan& plan) {
+  const int nz = r1 ? 2 : 1;
+  std::vector<const Op*> o0, o1;
+  for (auto* l : lists0) for (auto& op : *l) o0.push_back(&op);
+  if (r1) for (auto* l : lists1) for (auto& op : *l) o1.push_back(&op);
+  size_t i = 0;
+  while (i < o0.size()) {
+    const Op& op = *o0[i];
+    if (op.kind == 1) {
+      PlanStep st;
+      st.kind = 1; st.nz = nz;
+      st.H.p[0] = r0.head(op, want_grad);
+      if (r1) st.H.p[1] = r1->head(*o1[i], want_grad);
+      st.flops = op.flops * B * nz;
+      plan.push_back(st);
+      ++i;
+      continue;
+    }
+    // try to start a chain here
+    size_t j = i;
+    std::vector<ChainStage> run;
+    size_t lds = 0;
+    double fl = 0;
+    while (chain_S > 0 && j < o0.size()) {
+      Tile tl;
+      if (!chain_tile(*o0[j], chain_S, chain_max_n, &tl)) break;
+      ChainStage cs{};
+      cs.p[0] = r0.conv(*o0[j]);
+      if (r1) cs.p[1] = r1->conv(*o1[j]);
+      bool vec = conv_vec_ok(cs.p[0]) && (!r1 || conv_vec_ok(cs.p[1]));
+      cs.variant = conv_chain_variant(tl, vec);
+      if (cs.variant < 0 || (o0[j]->pro && !vec)) break;
+      cs.g = conv_make_geo(cs.p[0], tl);
+      size_t need = (size_t)cs.g.total * sizeof(float);
+      if (need > 160 * 1024) break;
+      lds = std::max(lds, need);
+      fl += o0[j]->flops * B * nz;
+      run.push_back(cs);
+      ++j;
+    }
+    if (run.size() >= 2) {
+      PlanStep st;
+      st.kind = 2; st.nz = nz;
+      st.chain_off = (int)tab.size(); st.chain_n = (int)run.size();
+      st.nblocks = (B + chain_S - 1) / chain_S;
+      st.chain_lds = lds; st.flops = fl;
+      tab.insert(tab.end(), run.begin(), run.end());
+      plan.push_back(st);
+      i = j;
+      continue;
+    }
+    PlanStep st;
+    st.kind = 0; st.nz = nz;
+    st.L.p[0] = r0.conv(op);
+    if (r1) st.L.p[1] = r1->conv(*o1[i]);
+    try {
+      st.tl = choose_tile(op, B);
+    } catch (const Unsupported& u) {
+      return fail(TREBI_UNSUPPORTED_CONFIG, "%s", u.msg.c_str());
+    }
+    if (st.tl.S * op.Lout > 16 * st.tl.MI || op.Npad % (16 * st.tl.NI * st.tl.NG) || 64 * st.tl.NG * st.tl.KS > 512 ||
+        (op.pro && (op.stride != 1 || op.Lin != op.Lout)) || !st.L.p[0].x || !st.L.p[0].out)
+      return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
+    st.flops = op.flops * B * nz;
+    plan.push_back(st);
+    ++i;
+  }
+  return 0;
+}
+
+int exec_plan(const Plan& plan, const ChainStage* dev_tab, int t_uniform, const long long* tptr, hipStream_t st,
+              GemmProfile* prof) {
+  for (const PlanStep& ps : plan) {
+    if (ps.kind == 1) {
+      HeadLaunch H = ps.H;
+      for (int z = 0; z < ps.nz; ++z) H.p[z].t = tptr;
+      HIPCHK(launch_head(H, ps.nz, st));
+      continue;
+    }
+    const bool timed = prof && prof->enabled;
+    if (timed) {
+      if (prof->used == prof->ev.size()) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        prof->ev.push_back({a, b});
+      }
+      HIPCHK(hipEventRecord(prof->ev[prof->used].first, st));
+    }
+    if (ps.kind == 2) {
+      HIPCHK(launch_conv_chain(dev_tab + ps.chain_off, ps.chain_n, ps.nz, ps.nblocks, ps.chain_lds, t_uniform, tptr, st));
+    } else {
+      ConvLaunch L = ps.L;
+      for (int z = 0; z < ps.nz; ++z) { L.p[z].t = tptr; L.p[z].t_uniform = t_uniform; }
+      HIPCHK(launch_conv(L, ps.nz, ps.tl, st));
+    }
+    if (timed) {
+      HIPCHK(hipEventRecord(prof->ev[prof->used].second, st));
+      prof->flops.push_back(ps.flops);
+      prof->used++;
     }
   }
   return 0;
@@ -1236,7 +1376,15 @@ struct trebi_sampler {
   GemmProfile prof;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   bool have_loop_time = false;
+  // launch plans (resolved once per set of caller pointers) and the device table of chained stages
+  std::vector<Plan> vf_grad, vf_nograd;   // one entry (both nets in one launch / a single net) or two
+  Plan unet_plan;
+  ChainStage* dev_tab = nullptr;
+  size_t dev_tab_cap = 0;
+  const void* plan_key[3] = {};
+  bool plans_valid = false;
   ~trebi_sampler() {
+    if (dev_tab) (void)hipFree(dev_tab);
     if (exec) (void)hipGraphExecDestroy(exec);
     if (arena) (void)hipFree(arena);
     if (ev_a) (void)hipEventDestroy(ev_a);
@@ -1303,6 +1451,61 @@ extern "C" int trebi_sampler_create(trebi_ctx* ctx, trebi_net* unet, trebi_net* 
 }
 extern "C" void trebi_sampler_destroy(trebi_sampler* s) { delete s; }
 
+// Resolve every network pass of the loop to launches for the caller's x / values / costs pointers.
+static int ensure_plans(trebi_sampler* s, float* x, float* values, float* costs) {
+  const void* key[3] = {x, values, costs};
+  if (s->plans_valid && memcmp(key, s->plan_key, sizeof key) == 0) return 0;
+  HIPCHK(hipDeviceSynchronize());          // a replay using the old table may still be in flight
+  const trebi_sampler_desc& d = s->d;
+  const int B = s->B, D = d.step.transition_dim;
+  const char* e_chain = getenv("TREBI_CHAIN");
+  const char* e_maxn = getenv("TREBI_CHAIN_MAXN");
+  const int chain_S = (e_chain && atoi(e_chain) == 0) || B > 1024 ? 0 : 1;
+  const int chain_max_n = e_maxn ? atoi(e_maxn) : 64;   // measured best at 64 candidates (wider layers want more workgroups)
+  std::vector<ChainStage> tab;
+  s->vf_grad.clear(); s->vf_nograd.clear(); s->unet_plan.clear();
+  Binding bu;
+  bu.x = x; bu.ldx = D; bu.out = s->x0; bu.ldo = D; bu.ws = s->ws_u;
+  Resolver ru{s->unet, s->unet->offsets(B), bu, B};
+  if (int e = build_plan({&s->unet->fwd}, {}, ru, nullptr, B, false, chain_S, chain_max_n, tab, s->unet_plan)) return e;
+  if (s->reward) {
+    Binding br, bc;
+    br.x = x; br.ldx = D; br.grad = s->rgrad; br.ldg = D; br.ws = s->ws_r; br.y = values;
+    bc = br; bc.grad = s->cgrad; bc.ws = s->ws_c; bc.y = costs;
+    Resolver rr{s->reward, s->reward->offsets(B), br, B};
+    if (s->cost) {
+      Resolver rc{s->cost, s->cost->offsets(B), bc, B};
+      if (s->dual) {
+        s->vf_grad.resize(1); s->vf_nograd.resize(1);
+        if (int e = build_plan({&s->cost->fwd, &s->cost->bwd}, {&s->reward->fwd, &s->reward->bwd}, rc, &rr, B, true,
+                               chain_S, chain_max_n, tab, s->vf_grad[0])) return e;
+        if (int e = build_plan({&s->cost->fwd}, {&s->reward->fwd}, rc, &rr, B, false, chain_S, chain_max_n, tab,
+                               s->vf_nograd[0])) return e;
+      } else {
+        s->vf_grad.resize(2); s->vf_nograd.resize(2);
+        if (int e = build_plan({&s->cost->fwd, &s->cost->bwd}, {}, rc, nullptr, B, true, chain_S, chain_max_n, tab, s->vf_grad[0])) return e;
+        if (int e = build_plan({&s->cost->fwd}, {}, rc, nullptr, B, false, chain_S, chain_max_n, tab, s->vf_nograd[0])) return e;
+        if (int e = build_plan({&s->reward->fwd, &s->reward->bwd}, {}, rr, nullptr, B, true, chain_S, chain_max_n, tab, s->vf_grad[1])) return e;
+        if (int e = build_plan({&s->reward->fwd}, {}, rr, nullptr, B, false, chain_S, chain_max_n, tab, s->vf_nograd[1])) return e;
+      }
+    } else {
+      s->vf_grad.resize(1); s->vf_nograd.resize(1);
+      if (int e = build_plan({&s->reward->fwd, &s->reward->bwd}, {}, rr, nullptr, B, true, chain_S, chain_max_n, tab, s->vf_grad[0])) return e;
+      if (int e = build_plan({&s->reward->fwd}, {}, rr, nullptr, B, false, chain_S, chain_max_n, tab, s->vf_nograd[0])) return e;
+    }
+  }
+  if (tab.size() > s->dev_tab_cap) {
+    if (s->dev_tab) (void)hipFree(s->dev_tab);
+    s->dev_tab = nullptr;
+    s->dev_tab_cap = tab.size() + 64;
+    HIPCHK(hipMalloc((void**)&s->dev_tab, s->dev_tab_cap * sizeof(ChainStage)));
+  }
+  if (!tab.empty()) HIPCHK(hipMemcpy(s->dev_tab, tab.data(), tab.size() * sizeof(ChainStage), hipMemcpyHostToDevice));
+  memcpy(s->plan_key, key, sizeof key);
+  s->plans_valid = true;
+  return 0;
+}
+
 // Enqueue the whole loop on `st` (diffusion.py:192-204 with the chosen sample function inlined).
 static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const* cond, const float* thr,
                         float* x, float* values, float* costs, float* chain, hipStream_t st, GemmProfile* prof) {
@@ -1312,12 +1515,13 @@ static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const
   StepP sp{};
   if (int e = make_step(&d.step, cond, &sp)) return e;
   HIPCHK(launch_init_x(sp, x, noise, B, chain, st));
-  if (d.kind == 0 || d.kind == 1) HIPCHK(hipMemsetAsync(costs, 0, B * sizeof(float), st));
-  if (d.kind == 0) HIPCHK(hipMemsetAsync(values, 0, B * sizeof(float), st));
+  // (a fill kernel, not a memset node: tiny memset nodes did not replay reliably inside the captured graph)
+  if (d.kind == 0 || d.kind == 1) HIPCHK(launch_fill_f(costs, B, 0.f, st));
+  if (d.kind == 0) HIPCHK(launch_fill_f(values, B, 0.f, st));
   const int Dv = s->reward ? s->reward->desc.transition_dim : D;
   if (s->reward && Dv < D) {      // guides.py:13 reads a column slice; the other columns get zero gradient
-    HIPCHK(hipMemsetAsync(s->rgrad, 0, per * sizeof(float), st));
-    if (s->cost) HIPCHK(hipMemsetAsync(s->cgrad, 0, per * sizeof(float), st));
+    HIPCHK(launch_fill_f(s->rgrad, (int)per, 0.f, st));
+    if (s->cost) HIPCHK(launch_fill_f(s->cgrad, (int)per, 0.f, st));
   }
   for (int i = T - 1; i >= 0; --i) {
     const long long* t = s->tbuf + (size_t)i * B;
@@ -1326,16 +1530,9 @@ static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const
       const bool dead = stopped && i != 0;                 // ... and y is only returned from the last step
       if (!(dead && d.skip_dead_evals)) {
         for (int k = 0; k < d.n_guide_steps; ++k) {
-          Binding br, bc;
-          br.x = x; br.ldx = D; br.grad = s->rgrad; br.ldg = D; br.t = t; br.t_uniform = i; br.ws = s->ws_r; br.y = values;
-          bc = br; bc.grad = s->cgrad; bc.ws = s->ws_c; bc.y = costs;
           const bool grad = !stopped;
-          if (s->cost && s->dual) {
-            if (int e = value_run(s->cost, bc, s->reward, &br, B, grad, st, prof)) return e;
-          } else {
-            if (s->cost) if (int e = value_run(s->cost, bc, nullptr, nullptr, B, grad, st, prof)) return e;
-            if (int e = value_run(s->reward, br, nullptr, nullptr, B, grad, st, prof)) return e;
-          }
+          for (const Plan& pl : (grad ? s->vf_grad : s->vf_nograd))
+            if (int e = exec_plan(pl, s->dev_tab, i, t, st, prof)) return e;
           if (grad)
             HIPCHK(launch_guide_update(sp, x, s->rgrad, s->cost ? s->cgrad : nullptr, costs, thr, t, s->plv, B, st));
           else if (d.skip_dead_evals)
@@ -1343,9 +1540,7 @@ static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const
         }
       }
     }
-    Binding bu;
-    bu.x = x; bu.ldx = D; bu.out = s->x0; bu.ldo = D; bu.t = t; bu.t_uniform = i; bu.ws = s->ws_u;
-    if (int e = run_ops(s->unet->fwd, s->unet, bu, nullptr, nullptr, nullptr, B, false, st, prof)) return e;
+    if (int e = exec_plan(s->unet_plan, s->dev_tab, i, t, st, prof)) return e;
     float* ch = chain ? chain + (size_t)(T - i) * per : nullptr;
     HIPCHK(launch_ddpm_update(sp, x, s->x0, noise + (size_t)(T - i) * per, t, s->plv, s->c1, s->c2, B, ch, st));
   }
@@ -1359,6 +1554,7 @@ extern "C" int trebi_sampler_run(trebi_sampler* s, const float* noise, const flo
   if (s->d.step.n_cond > 0 && !cond) return fail(TREBI_BAD_ARG, "cond is null");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(s->ctx->device));
+  if (int e = ensure_plans(s, x, values, costs)) return e;
   if (s->prof.enabled) {          // profiled run: plain launches bracketed by events
     s->prof.reset();
     HIPCHK(hipEventRecord(s->ev_a, st));
