@@ -16,6 +16,7 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <array>
 
 using namespace trebi;
 
@@ -835,59 +836,67 @@ void build_value(Builder& B, const ArchPlan& a) {
 // ------------------------------------------------------------------------------------
 int gcd(int a, int b) { return b ? gcd(b, a % b) : a; }
 
-Tile choose_tile(const Op& op, int B) {
-  Tile t;
+// Pick the tile of one layer for a batch of B candidates in nz nets per launch.  The kernel needs ~200
+// VGPRs, so one 512-thread workgroup is resident per compute unit: a launch takes ceil(workgroups / 256)
+// rounds of one workgroup lifetime each.  Enumerate the shapes the kernel is instantiated for and take the
+// cheapest by a small cost model (fixed per-workgroup latency + matrix-core time per SIMD + staging).
+Tile choose_tile(const Op& op, int B, int nz = 1) {
   int Lout = op.Lout;
   if (Lout > 128) unsupported("sequence length %d > 128 is not tiled", Lout);
-  int S = Lout >= 16 ? 1 : 16 / Lout;
   auto mi_for = [&](int s) {
     int rows = s * Lout, m = (rows + 15) / 16;
     return m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : 8;
   };
-  int units = op.Npad / 16;
-  int tnu = 1;                                      // tile width in 16-column units
+  const int units = op.Npad / 16;
+  int tnu = 1;                                      // narrowest tile in 16-column units
   if (op.gn) {
-    int l = op.gnw.gch / gcd(op.gnw.gch, 16) * 16;  // lcm(gch, 16)
+    int l = op.gnw.gch / gcd(op.gnw.gch, 16) * 16;  // lcm(gch, 16): whole GroupNorm groups per tile
     tnu = l / 16;
     if (op.N % GN_GROUPS || op.Npad != op.N || units % tnu || op.gnw.gch % 4)
       unsupported("GroupNorm(8) over %d channels does not tile (channels must be a multiple of 32)", op.N);
   }
   if (op.osplit && op.osplit % (16 * tnu)) unsupported("phase split %d not a multiple of the tile", op.osplit);
-  int NI = 1, NG = tnu;
-  if (NG > 8) {
-    if (NG % 2 || NG / 2 > 8) unsupported("column tile of %d is too wide", 16 * tnu);
-    NI = 2;
-    NG /= 2;
+  const int KK = (op.ntaps * op.Cin_p + op.Cin2_p) / 16;
+  ConvP q{};
+  q.Lout = op.Lout; q.stride = op.stride; q.ntaps = op.ntaps; q.Cin_p = op.Cin_p;
+  q.x2 = op.src2.id != NONE ? (const float*)1 : nullptr;
+  q.Cin2_p = op.Cin2_p; q.gn = op.gn; q.gch = op.gn ? op.gnw.gch : 1;
+  q.Lin = op.Lin; q.pro = op.pro ? 1 : 0; q.tbias = op.tbias;
+  q.res = op.res.id != NONE ? (const float*)1 : nullptr;
+  q.tap_lo = op.tap_lo; q.pad = op.pad;
+  const int R = (op.Lout - 1) * op.stride + op.ntaps;
+  Tile best{};
+  double best_cost = -1;
+  const int S0 = Lout >= 16 ? 1 : 16 / Lout;
+  for (int S = S0; S * Lout <= 128 && (S == S0 || S <= B); S *= 2) {
+    const int MI = mi_for(S);
+    for (int NI = 1; NI <= 2; ++NI) {
+      if (MI == 8 && NI == 2) continue;             // not instantiated
+      for (int NG = tnu; NG <= 8; NG += tnu) {
+        const int tu = NI * NG;                     // tile width in 16-column units
+        if (units % tu || tu % tnu) continue;
+        if (op.osplit && op.osplit % (16 * tu)) continue;
+        int KS = std::max(1, std::min(8 / NG, std::max(1, KK / 4)));
+        Tile t{MI, NI, NG, KS, S};
+        const size_t lds = conv_lds_bytes(q, t);
+        if (lds > 160 * 1024) continue;
+        const long wgs = (long)((B + S - 1) / S) * (units / tu) * nz;
+        const long rounds = (wgs + 255) / 256;
+        const int chunk = (KK + KS - 1) / KS;
+        const double mfma = 32.0 * 4 * MI * NI * chunk;                  // cycles of one wave's matrix work
+        const double simd = mfma * std::max(1.0, NG * KS / 4.0);         // waves of a SIMD share its matrix core
+        const double nthr = 64.0 * NG * KS;
+        const double stage = 30.0 * ((double)S * R * op.Cin_p / 4 * (op.pro ? 3 : 1) +
+                                     (double)S * Lout * op.Cin2_p / 4) / nthr;
+        const double epi = 60.0 * (16.0 * MI * 16 * tu / 4) / nthr;
+        const double wload = 8.0 * chunk * NI;                           // issue + latency share of the weight stream
+        const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; }
+      }
+    }
   }
-  int KK = (op.ntaps * op.Cin_p + op.Cin2_p) / 16;
-  // large batches: more candidates per workgroup (weights are reused across more rows) and two
-  // column sub-tiles per wave, as long as the grid still covers the chip several times over
-  long wgs = (long)((B + S - 1) / S) * (units / tnu);
-  auto lds_of = [&](int s, int ni, int ng, int ks) {
-    ConvP p{};
-    p.Lout = op.Lout; p.stride = op.stride; p.ntaps = op.ntaps; p.Cin_p = op.Cin_p;
-    p.x2 = op.src2.id != NONE ? (const float*)1 : nullptr;
-    p.Cin2_p = op.Cin2_p; p.gn = op.gn; p.gch = op.gn ? op.gnw.gch : 1;
-    p.Lin = op.Lin; p.pro = op.pro ? 1 : 0; p.tbias = op.tbias;
-    p.res = op.res.id != NONE ? (const float*)1 : nullptr;
-    Tile tt{mi_for(s), ni, ng, ks, s};
-    return conv_lds_bytes(p, tt);
-  };
-  while (wgs >= 2048 && mi_for(S * 2) <= 4 && S * 2 * Lout <= 64 && lds_of(S * 2, NI, NG, 1) <= 96 * 1024) {
-    S *= 2;
-    wgs /= 2;
-  }
-  if (wgs >= 2048 && NI == 1 && (units / tnu) % 2 == 0 && mi_for(S) <= 4 &&
-      !(op.osplit && op.osplit % (32 * tnu))) {
-    NI = 2;                                         // 2*tnu units still hold whole GroupNorm groups
-    wgs /= 2;
-  }
-  int MI = mi_for(S);
-  int KS = std::min(8 / NG, std::max(1, KK / 4));
-  if (KS < 1) KS = 1;
-  t = {MI, NI, NG, KS, S};
-  if (lds_of(S, NI, NG, KS) > 160 * 1024) unsupported("layer %s needs more than 160 KiB of LDS", op.name.c_str());
-  return t;
+  if (best_cost < 0) unsupported("layer %s needs more than 160 KiB of LDS", op.name.c_str());
+  return best;
 }
 
 struct Resolver {
@@ -942,8 +951,9 @@ struct GemmProfile {
   bool enabled = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   std::vector<double> flops;
+  std::vector<std::string> names;  // layer + tile of each timed launch (TREBI_PROFILE_DUMP diagnostics)
   size_t used = 0;
-  void reset() { used = 0; flops.clear(); }
+  void reset() { used = 0; flops.clear(); names.clear(); }
   ~GemmProfile() {
     for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
@@ -974,7 +984,7 @@ int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, 
     if (n1) L.p[1] = r1.conv((*ops1)[i]);
     Tile tl;
     try {
-      tl = choose_tile(op, B);
+      tl = choose_tile(op, B, nz);
     } catch (const Unsupported& u) {
       return fail(TREBI_UNSUPPORTED_CONFIG, "%s", u.msg.c_str());
     }
@@ -1015,6 +1025,7 @@ struct PlanStep {
   int chain_off = 0, chain_n = 0, nblocks = 0;
   size_t chain_lds = 0;
   double flops = 0;                // algorithmic, whole batch, all nets of the launch
+  std::string name;
 };
 typedef std::vector<PlanStep> Plan;
 
@@ -1081,6 +1092,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
       st.chain_off = (int)tab.size(); st.chain_n = (int)run.size();
       st.nblocks = (B + chain_S - 1) / chain_S;
       st.chain_lds = lds; st.flops = fl;
+      st.name = "chain[" + std::to_string(run.size()) + "] " + o0[i]->name + " .. " + o0[j - 1]->name;
       tab.insert(tab.end(), run.begin(), run.end());
       plan.push_back(st);
       i = j;
@@ -1091,7 +1103,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
     st.L.p[0] = r0.conv(op);
     if (r1) st.L.p[1] = r1->conv(*o1[i]);
     try {
-      st.tl = choose_tile(op, B);
+      st.tl = choose_tile(op, B, nz);
     } catch (const Unsupported& u) {
       return fail(TREBI_UNSUPPORTED_CONFIG, "%s", u.msg.c_str());
     }
@@ -1099,6 +1111,12 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
         (op.pro && (op.stride != 1 || op.Lin != op.Lout)) || !st.L.p[0].x || !st.L.p[0].out)
       return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
     st.flops = op.flops * B * nz;
+    {
+      char tb[96];
+      snprintf(tb, sizeof tb, " MI%d NI%d NG%d KS%d S%d grid %dx%d", st.tl.MI, st.tl.NI, st.tl.NG, st.tl.KS, st.tl.S,
+               (B + st.tl.S - 1) / st.tl.S, op.Npad / (16 * st.tl.NI * st.tl.NG));
+      st.name = op.name + (op.pro ? " (bwd)" : "") + tb;
+    }
     plan.push_back(st);
     ++i;
   }
@@ -1134,6 +1152,7 @@ int exec_plan(const Plan& plan, const ChainStage* dev_tab, int t_uniform, const 
     if (timed) {
       HIPCHK(hipEventRecord(prof->ev[prof->used].second, st));
       prof->flops.push_back(ps.flops);
+      prof->names.push_back(ps.name);
       prof->used++;
     }
   }
@@ -1604,6 +1623,22 @@ extern "C" int trebi_sampler_get_profile(trebi_sampler* s, double* gemm_us_total
     HIPCHK(hipEventElapsedTime(&ms, s->prof.ev[i].first, s->prof.ev[i].second));
     us += 1e3 * ms;
     fl += s->prof.flops[i];
+  }
+  if (const char* path = getenv("TREBI_PROFILE_DUMP")) {   // diagnostics: per-layer totals of the profiled run
+    std::map<std::string, std::array<double, 3>> agg;
+    for (size_t i = 0; i < s->prof.used && i < s->prof.names.size(); ++i) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, s->prof.ev[i].first, s->prof.ev[i].second));
+      auto& a = agg[s->prof.names[i]];
+      a[0] += 1; a[1] += 1e3 * ms; a[2] += s->prof.flops[i];
+    }
+    if (FILE* f = fopen(path, "w")) {
+      fprintf(f, "launches\ttotal_us\tavg_us\tTFLOPs\tlayer\n");
+      for (auto& kv : agg)
+        fprintf(f, "%d\t%.1f\t%.2f\t%.2f\t%s\n", (int)kv.second[0], kv.second[1], kv.second[1] / kv.second[0],
+                kv.second[2] / (kv.second[1] * 1e-6) / 1e12, kv.first.c_str());
+      fclose(f);
+    }
   }
   float lms = 0;
   HIPCHK(hipEventElapsedTime(&lms, s->ev_a, s->ev_b));

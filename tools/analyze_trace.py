@@ -1,5 +1,5 @@
 import csv, collections, glob, sys
-f=glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')[0]
+f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv', recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 d=collections.defaultdict(list)

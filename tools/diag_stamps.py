@@ -21,13 +21,13 @@ lib.trebi_debug_read_stamps.argtypes = [C.POINTER(C.c_uint64)]
 buf = (C.c_uint64 * 32)()
 run = (lambda: net.value_and_input_grad(x, t)) if kind == 'value' else (lambda: net(x, None, t))
 nops = 60 if kind == 'value' else 45
-print('op  total_cyc  us(100MHz clk)  clkGHz | phases: preload stage wait_bar prologue kloop bar+partials reduce stats epilogue')
+print('op  total_cyc  us(100MHz clk)  clkGHz | phases: preload stage wait_bar prologue kloop bar+partials epilogue')
 for n in range(nops):
     os.environ['TREBI_STOP_AFTER'] = str(n)
     for _ in range(3):
         run(); torch.cuda.synchronize()
     lib.trebi_debug_read_stamps(buf)
     s = list(buf)
-    cyc = [s[i + 1] - s[i] for i in range(9)]
+    cyc = [s[i + 1] - s[i] for i in range(6)] + [s[9] - s[6]]
     tot = s[9] - s[0]; real = (s[25] - s[16]) / 100.0
     print(f'{n:3d} {tot:8d} {real:7.2f} {tot / max(real, 1e-9) / 1e3:5.2f} |', ' '.join(f'{c:6d}' for c in cyc))
