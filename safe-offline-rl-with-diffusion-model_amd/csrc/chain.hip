@@ -1,0 +1,561 @@
+// chain.hip -- resident chains: consecutive layers of a network in ONE launch, activations kept in LDS.
+//
+// At planning batch sizes a layer's matrix work takes ~1 us while a kernel that reads its input from
+// global memory, stages it, runs, and stores the result takes 7-9 us of mostly latency.  A workgroup that
+// owns S whole candidates and ALL output columns of a layer depends only on its own earlier outputs, so a
+// run of such layers executes here as stages of one kernel:
+//   * a stage's output is written straight into the LDS layout its consumers read (canonical layout, see
+//     RStage in common.h) -- no global round trip, no store drain between layers; tensors that something
+//     outside the chain needs (skip connections, saved GroupNorm operands, the chain's result) are also
+//     stored to global memory, fire and forget;
+//   * the packed weights of the NEXT stage's first reduction block are requested before this stage's
+//     epilogue, and within a stage the weight stream is double-buffered in registers;
+//   * stages are separated by an LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier); outstanding global
+//     stores are drained only in front of a stage that reads a global tensor written earlier in the chain.
+// The arithmetic is the same as conv_body (conv.hip): v_mfma_f32_16x16x4_f32 implicit GEMM, split-K through
+// LDS, GroupNorm(8) + Mish (+ time bias, residual) per (candidate, group) team, GroupNorm backward as a
+// prologue of the backward layers -- here with the team's operands held in registers between the passes.
+#include "device_util.h"
+
+namespace trebi {
+
+#ifdef TREBI_STAMPS          // diagnostic build: cycle stamps of workgroup (0,0,0) per (launch shape, stage, phase)
+__device__ unsigned long long g_cstamps[96 * 48 * 8];
+extern "C" int trebi_debug_read_cstamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamps), sizeof(g_cstamps));
+}
+#define CSTAMP(ph)                                                                                 \
+  do {                                                                                             \
+    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)                                    \
+      g_cstamps[((size_t)skey * 48 + sidx) * 8 + (ph)] = __builtin_amdgcn_s_memtime();             \
+  } while (0)
+#else
+#define CSTAMP(ph)
+#endif
+
+namespace {
+
+constexpr int WREG = 8;            // float4 weight registers per half of the double buffer
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void drain_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Request the weights of reduction steps [kb, kb + WREG/NI) of this wave's K range into w (flat [u][ni]).
+__device__ __forceinline__ void wload(f32x4 (&w)[WREG], const float* pw, unsigned wstep, unsigned wlane, int NI,
+                                      int kb, int ke) {
+  const float* wu = pw + (size_t)kb * wstep + wlane;
+  if (NI == 1) {
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+      if (kb + u < ke) w[u] = gld4(wu);
+      wu += wstep;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < WREG / 2; ++u) {
+      if (kb + u < ke) {
+        w[2 * u] = gld4(wu);
+        w[2 * u + 1] = gld4(wu + 64);
+      }
+      wu += wstep;
+    }
+  }
+}
+
+// First weight block of a stage, for the wave `wave` (any stage: used for stage 0 and as the prefetch).
+__device__ __forceinline__ void wfirst(const RStage& st, int z, int wave, int lane, f32x4 (&w)[WREG]) {
+  const int NG = st.g.NG, KS = st.g.KS, NI = st.NI;
+  if (wave >= NG * KS) return;
+  const int ks = FastDiv(NG, st.g.mNG).div(wave), ng = wave - ks * NG;
+  const int Npad = st.p[z].Npad;
+  const int kb = ks * st.g.chunk;
+  const int ke = kb + st.g.chunk < st.g.KK ? kb + st.g.chunk : st.g.KK;
+  const unsigned wlane = (unsigned)(((lane >> 4) * Npad + ng * NI * 16 + (lane & 15)) * 4);
+  wload(w, st.p[z].w, (unsigned)Npad * 16u, wlane, NI, kb, ke);
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* sp, int left, bool vec) {
+  return vec ? load4<true>(sp, left) : load4<false>(sp, left);
+}
+
+template <int MI, int NI>
+__device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, const int z, float* smem, const int tid,
+                                         const int b0, int t_uniform, const long long* tptr,
+                                         f32x4 (&wreg)[2][WREG], int skey, int sidx) {
+  constexpr int WH = WREG / NI;    // reduction steps per register half
+  CSTAMP(0);
+  const ConvP& p = st.p[z];
+  const ConvGeo& G = st.g;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const float* px = p.x;  const float* pw = p.w;  float* pout = p.out;
+  int ldx = p.ldx, Cin = p.Cin, Lin = p.Lin, Lout = p.Lout, stride = p.stride, B = p.B, N = p.N, Npad = p.Npad;
+  int S = G.S, NG = G.NG, KS = G.KS, nthr = G.nthr, TM = G.TM, TN = G.TN, TNp = G.TNp, R = G.R, ldA = G.ldA,
+      ld2 = G.ld2;
+  int cbpt = G.cbpt, KK1 = G.KK1, KK = G.KK, chunk = G.chunk, nv = G.nv, fh = G.fh;
+  int Rb = st.Rb, a0 = st.a0, Rb2 = st.Rb2, h2 = st.h2;
+  PIN(px); PIN(pw); PIN(pout); PIN(ldx); PIN(Cin); PIN(Lin); PIN(Lout); PIN(stride); PIN(B); PIN(N); PIN(Npad);
+  PIN(S); PIN(NG); PIN(KS); PIN(nthr); PIN(TM); PIN(TN); PIN(TNp); PIN(R); PIN(ldA); PIN(ld2);
+  PIN(cbpt); PIN(KK1); PIN(KK); PIN(chunk); PIN(nv); PIN(fh); PIN(Rb); PIN(a0); PIN(Rb2); PIN(h2);
+  const bool has2 = p.Cin2_p != 0, haspro = p.pro != 0, hasres = p.res != nullptr || st.resRes,
+             hastb = p.tbias != nullptr, hasgn = p.gn != 0;
+  const bool vec = st.vec != 0;
+  const bool active = tid < nthr;
+  float* slab = smem + st.oSrc;
+  float* slab2 = smem + st.o2;
+  float* resb = smem + st.oR;
+  float* dreg = smem + st.oD;
+  float* red = smem + st.oRed;
+  float* red2 = smem + st.oRed2;
+  float* colp = smem + st.oColp;         // [4][TN]: bias, gamma, beta, bias2
+  float* tbrow = smem + st.oTb;          // [S][TN]
+  const FastDiv dLout(Lout, G.mLout), dTN4(G.tn4, G.mTN4), dTN(TN, G.mTN);
+  const int nvs = (B - b0 < S) ? B - b0 : S;       // candidates of this tile that exist
+
+  const int g = lane >> 4, lr = lane & 15;
+  const int ks = FastDiv(NG, G.mNG).div(wave), ng = wave - ks * NG;
+  const int k_begin = active ? ks * chunk : 0;
+  const int k_end = active ? ((k_begin + chunk < KK) ? k_begin + chunk : KK) : 0;
+  const unsigned wlane = (unsigned)((g * Npad + ng * NI * 16 + lr) * 4);
+  const unsigned wstep = (unsigned)Npad * 16u;
+
+  // ---- phase A: everything this stage reads from global memory --------------------------------
+  // GroupNorm-backward operands of this thread's team (registers): saved mish'(z)*gamma and xhat
+  const int ts_pro = G.ts_pro;
+  const int pteam = ts_pro == 64 ? (tid >> 6) : (tid >> 4), ptl = tid & (ts_pro - 1);
+  f32x4 pg_[2], px_[2];
+  int po_[2] = {-1, -1}, pi_[2] = {0, 0};
+  float prstd = 0.f;
+  bool pinst = false;
+  if (haspro && active) {
+    const int inst = pteam;                          // host guarantees S*8 <= number of teams
+    const int s = inst >> 3, gi = inst & 7;
+    if (inst < S * GN_GROUPS && s < nvs) {
+      pinst = true;
+      const int gch = p.pro_gch, pg4 = G.pgch4, cnt4 = G.pcnt4;
+      const FastDiv dG(pg4, G.mPGch4);
+      prstd = gld(p.pro_stats + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2 + 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = ptl + j * ts_pro;
+        if (e < cnt4) {
+          const int li = dG.div(e), c = gi * gch + 4 * (e - li * pg4);
+          po_[j] = (s * Rb + st.pr0 + li) * ldA + c;
+          pi_[j] = st.proRes ? (s * (Lin + 4) + 2 + li) * ldA + c : po_[j];
+          const unsigned go = ((unsigned)(b0 + s) * Lin + li) * (unsigned)Cin + c;
+          pg_[j] = gld4(p.pro_g + go);
+          px_[j] = gld4(p.pro_y + go);
+        }
+      }
+    }
+  }
+  if (active) {
+    float c0 = 0.f, c1 = 1.f, c2 = 0.f, c3 = 0.f;
+    const bool colt = tid < TN;
+    if (colt) {
+      const int n = tid;
+      const bool ok = n < N;
+      if (ok && p.bias) c0 = gld(p.bias + n);
+      if (ok && hasgn) { c1 = gld(p.gamma + n); c2 = gld(p.beta + n); }
+      if (ok && p.bias2) c3 = gld(p.bias2 + n);
+    }
+    auto tb_load = [&](int e) -> float {
+      int s = dTN.div(e), c = e - s * TN;
+      if (s >= nvs || c >= N) return 0.f;
+      long long tt = t_uniform >= 0 ? t_uniform : gldll(tptr + b0 + s);
+      tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
+      return gld(p.tbias + (unsigned)tt * (unsigned)N + c);
+    };
+    float tbv[2] = {0.f, 0.f};
+    if (hastb) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < S * TN) tbv[u] = tb_load(tid + u * nthr);
+    }
+    // identity residual from global memory -> tile [TM][TNp]
+    if (hasres && !st.resRes) {
+      const int nRes4 = G.nRes4;
+      for (int e = tid; e < nRes4; e += nthr) {
+        int row = dTN4.div(e), c4 = e - row * G.tn4;
+        int left = N - 4 * c4;
+        if (row >= nvs * Lout) left = 0;
+        const float* sp = p.res + ((unsigned)b0 * Lout + row) * (unsigned)p.ldres + 4 * c4;
+        *(f32x4*)&resb[row * TNp + 4 * c4] = G.vecr ? load4<true>(sp, left) : load4<false>(sp, left);
+      }
+    }
+    // primary source from global memory -> slab [S][R][ldA] with a zero halo (with a resident gradient
+    // only the halo: the prologue writes the rows)
+    if (!st.srcRes) {
+      const FastDiv dC4(G.c4n, G.mC4), dNv(nv, G.mNv);
+      const int c4n = G.c4n, total = st.proRes ? 0 : G.nValid4, vlo = G.vlo;
+      for (int base = tid; base < total; base += 4 * nthr) {
+        f32x4 v[4];
+        int so[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int idx = base + u * nthr;
+          so[u] = -1;
+          if (idx < total) {
+            int rowv = dC4.div(idx), c4 = idx - rowv * c4n;
+            int s = dNv.div(rowv), i = rowv - s * nv;
+            so[u] = (s * R + fh + i) * ldA + 4 * c4;
+            unsigned grow = (unsigned)(b0 + s) * Lin + vlo + i;
+            int left = s < nvs ? Cin - 4 * c4 : 0;
+            v[u] = ld4(px + grow * (unsigned)ldx + 4 * c4, left, vec);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (so[u] >= 0) *(f32x4*)&slab[so[u]] = v[u];
+      }
+      const FastDiv dHr(G.hr, G.mHr);
+      const int nh = G.nHalo4, hr = G.hr;
+      for (int idx = tid; idx < nh; idx += nthr) {
+        int h = dC4.div(idx), c4 = idx - h * c4n;
+        int s = dHr.div(h), k = h - s * hr;
+        int j = k < fh ? k : k + nv;
+        *(f32x4*)&slab[(s * R + j) * ldA + 4 * c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (has2 && !st.x2Res) {            // second source rows at the output positions -> slab2 [S*Lout][ld2]
+      const FastDiv dC4(G.c4n2, G.mC4b);
+      const int c4n = G.c4n2, total = G.nX24, C2 = p.Cin2;
+      const float* p2 = p.x2;
+      const unsigned ldx2 = p.ldx2;
+      for (int base = tid; base < total; base += 2 * nthr) {
+        f32x4 v[2];
+        int so[2] = {-1, -1};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          int idx = base + u * nthr;
+          if (idx < total) {
+            int row = dC4.div(idx), c4 = idx - row * c4n;
+            so[u] = row * ld2 + 4 * c4;
+            int left = row < nvs * Lout ? C2 - 4 * c4 : 0;
+            v[u] = ld4(p2 + ((unsigned)b0 * Lout + row) * ldx2 + 4 * c4, left, vec);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (so[u] >= 0) *(f32x4*)&slab2[so[u]] = v[u];
+      }
+    }
+    // zero halo rows of the resident destination (2 in front, 2 behind every candidate)
+    if (st.dstRes) {
+      const int ld4n = st.ldD >> 2, tot = S * 4 * ld4n;
+      const FastDiv dL4(ld4n, st.mLd4);
+      for (int idx = tid; idx < tot; idx += nthr) {
+        int h = dL4.div(idx), c4 = idx - h * ld4n;
+        int s = h >> 2, k = h & 3;
+        int row = s * st.RbD + (k < 2 ? k : st.Ld + k);
+        *(f32x4*)&dreg[row * st.ldD + 4 * c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (colt) {
+      colp[tid] = c0;
+      colp[TN + tid] = c1;
+      colp[2 * TN + tid] = c2;
+      colp[3 * TN + tid] = c3;
+    }
+    if (hastb) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < S * TN) tbrow[tid + u * nthr] = tbv[u];
+      for (int e = tid + 2 * nthr; e < S * TN; e += nthr) tbrow[e] = tb_load(e);
+    }
+  }
+  CSTAMP(1);
+  if ((!st.srcRes && !st.proRes) || (has2 && !st.x2Res)) lds_barrier();     // staged operands visible to every wave
+
+  // ---- prologue: GroupNorm backward of the producing Conv1dBlock ----------------------------------
+  //   d = dA * mish'(z)*gamma;  dY = rstd * (d - mean_g(d) - xhat * mean_g(d * xhat))
+  // dA is read from the staged slab or from the resident gradient (left untouched: the residual path of the
+  // next layer reads it again); dY always lands in the slab the K loop reads.
+  if (haspro) {
+    const float* pin = smem + (st.proRes ? st.oPro : st.oSrc);
+    if (active && pteam < S * GN_GROUPS) {
+      f32x4 d[2];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (pinst && po_[j] >= 0) {
+          d[j] = *(const f32x4*)&pin[pi_[j]] * pg_[j];
+          s1 += hsum(d[j]);
+          s2 += hsum(d[j] * px_[j]);
+        }
+      }
+      const float icnt = 1.f / (float)(G.pcnt4 * 4);
+      const float m1 = team_sum(s1, ts_pro) * icnt, m2 = team_sum(s2, ts_pro) * icnt;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (pinst && po_[j] >= 0) *(f32x4*)&slab[po_[j]] = (d[j] - m1 - px_[j] * m2) * prstd;
+    }
+    lds_barrier();
+  }
+
+  CSTAMP(2);
+  // ---- implicit GEMM on the f32 matrix cores, weights double-buffered in registers ------------
+  f32x4 acc[MI][NI], acc2[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  if (active) {
+    int rowA[MI], row2[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      int r = mi * 16 + lr;
+      int s = dLout.div(r), lo = r - s * Lout;
+      bool ok = s < S;
+      rowA[mi] = ok ? (s * Rb + lo * stride + a0) * ldA + 4 * g : 4 * g;
+      row2[mi] = ok ? (s * Rb2 + h2 + lo) * ld2 + 4 * g : 4 * g;
+    }
+    const FastDiv dCb(cbpt, G.mCbpt);
+    int cb, aoff;
+    {
+      int tau = dCb.div(k_begin);
+      cb = k_begin - tau * cbpt;
+      aoff = tau * ldA + cb * 16;
+    }
+    auto compute = [&](const f32x4 (&w)[WREG], int kbase) {
+#pragma unroll
+      for (int u = 0; u < WH; ++u) {
+        const int kk = kbase + u;
+        if (kk < k_end) {
+          f32x4 a[MI];
+          if (kk < KK1) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                  acc[mi][ni] =
+                      __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], w[u * NI + ni][j], acc[mi][ni], 0, 0, 0);
+            aoff += 16;
+            if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
+          } else {
+            const int a2 = (kk - KK1) * 16;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab2[row2[mi] + a2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                  acc2[mi][ni] =
+                      __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], w[u * NI + ni][j], acc2[mi][ni], 0, 0, 0);
+          }
+        }
+      }
+    };
+    for (int kb = k_begin; kb < k_end; kb += 2 * WH) {
+      const bool more = kb + WH < k_end;
+      if (more) wload(wreg[1], pw, wstep, wlane, NI, kb + WH, k_end);
+      compute(wreg[0], kb);
+      if (more) {
+        if (kb + 2 * WH < k_end) wload(wreg[0], pw, wstep, wlane, NI, kb + 2 * WH, k_end);
+        compute(wreg[1], kb + WH);
+      }
+    }
+  }
+  CSTAMP(3);
+  // the next stage's first weight block travels while this stage reduces and normalises
+  if (nx) wfirst(*nx, z, wave, lane, wreg[0]);
+
+  // ---- split-K partials -> LDS.  C/D layout: col = lane&15, row = 4*(lane>>4) + reg -------
+  const int kstride = TM * TNp;
+  if (active) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int o = ks * kstride + (mi * 16 + g * 4 + q) * TNp + (ng * NI + ni) * 16 + lr;
+          red[o] = acc[mi][ni][q];
+          if (has2) red2[o] = acc2[mi][ni][q];
+        }
+  }
+  lds_barrier();
+  CSTAMP(4);
+  if (!active) return;
+
+  const FastDiv dOs(p.osplit > 0 ? p.osplit : 1, G.mOs);
+  const int osplit = p.osplit;
+  const unsigned ldo = p.ldo;
+  const bool veco = G.veco != 0;
+  const int RbR = st.RbR, hR = st.hR, ldR = st.ldR, RbD = st.RbD, ldD = st.ldD;
+  const bool dstRes = st.dstRes != 0;
+  // finish 4 adjacent output columns of (candidate s, position lo): time bias, second-source sum,
+  // residual, then the resident copy and / or the global store
+  auto finish = [&](f32x4 v, int s, int lo, int col) {
+    const int row = s * Lout + lo;
+    if (hastb) v += *(const f32x4*)&tbrow[s * TN + col];
+    if (has2) {
+      f32x4 v2 = *(const f32x4*)&colp[3 * TN + col];
+      for (int k = 0; k < KS; ++k) v2 += *(const f32x4*)&red2[k * kstride + row * TNp + col];
+      v += v2;
+    }
+    if (hasres) v += *(const f32x4*)&resb[(s * RbR + hR + lo) * ldR + col];
+    int pos = lo, ch = col;
+    if (osplit > 0) {
+      int ph = dOs.div(col);
+      ch = col - ph * osplit;
+      pos = 2 * lo + ph;
+    }
+    if (dstRes) *(f32x4*)&dreg[(s * RbD + 2 + pos) * ldD + ch] = v;
+    if (pout) {
+      const unsigned orow = (unsigned)b0 * Lout + row;
+      float* dst = osplit > 0 ? pout + (orow * 2 + (pos - 2 * lo)) * ldo + ch : pout + orow * ldo + col;
+      if (veco) {
+        if (col < N) gst4(dst, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < N) gst(dst + e, v[e]);
+      }
+    }
+  };
+
+  if (hasgn) {
+    // split-K reduce + bias, GroupNorm statistics, normalise, Mish: a team per (candidate, group), the
+    // team's values (at most 2 float4 per lane, checked on the host) stay in registers between passes
+    const int gch = p.gch, g4 = G.gch4, cnt4 = G.cnt4, gpt = G.gpt, ninst = S * gpt;
+    const int ts = G.ts_epi;
+    const int team = ts == 64 ? (tid >> 6) : (tid >> 4), tl = tid & (ts - 1),
+              nteams = ts == 64 ? (nthr >> 6) : (nthr >> 4);
+    const FastDiv dG(g4, G.mGch4), dGpt(gpt, G.mGpt);
+    const float icnt = 1.f / (float)(cnt4 * 4);
+    float* sy = p.save_y;
+    float* sg = p.save_g;
+    for (int inst = team; inst < ninst; inst += nteams) {
+      int s = dGpt.div(inst), gi = inst - s * gpt;
+      if (s >= nvs) continue;
+      f32x4 v[2];
+      int lo_[2], c_[2];
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = tl + j * ts;
+        lo_[j] = -1;
+        v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (e < cnt4) {
+          int lo = dG.div(e), c = gi * gch + 4 * (e - lo * g4);
+          lo_[j] = lo;
+          c_[j] = c;
+          const int o = (s * Lout + lo) * TNp + c;
+          f32x4 a = *(const f32x4*)&colp[c];
+          for (int k = 0; k < KS; ++k) a += *(const f32x4*)&red[k * kstride + o];
+          v[j] = a;
+          sum += hsum(a);
+        }
+      }
+      const float mean = team_sum(sum, ts) * icnt;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (lo_[j] >= 0) {
+          f32x4 d = v[j] - mean;
+          sq += hsum(d * d);
+        }
+      const float rstd = 1.f / sqrtf(team_sum(sq, ts) * icnt + GN_EPS);
+      if (tl == 0 && p.save_stats) {
+        float* o = p.save_stats + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2;
+        gst(o, mean);
+        gst(o + 1, rstd);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (lo_[j] >= 0) {
+          const int col = c_[j];
+          f32x4 xh = (v[j] - mean) * rstd;
+          f32x4 ga = *(const f32x4*)&colp[TN + col];
+          f32x4 zz = xh * ga + *(const f32x4*)&colp[2 * TN + col];
+          f32x4 m, dm;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float a, b;
+            mish_both(zz[q], &a, &b);
+            m[q] = a;
+            dm[q] = b;
+          }
+          if (sy) {
+            unsigned so = ((unsigned)b0 * Lout + s * Lout + lo_[j]) * (unsigned)N + col;
+            gst4(sy + so, xh);
+            gst4(sg + so, dm * ga);
+          }
+          finish(m, s, lo_[j], col);
+        }
+    }
+  } else {
+    const int nitems = G.nRes4;            // TM * TN / 4
+    for (int e = tid; e < nitems; e += nthr) {
+      int row = dTN4.div(e), col = 4 * (e - row * G.tn4);
+      if (row >= nvs * Lout || col >= N) continue;
+      int s = dLout.div(row);
+      f32x4 v = *(const f32x4*)&colp[col];
+      for (int k = 0; k < KS; ++k) v += *(const f32x4*)&red[k * kstride + row * TNp + col];
+      finish(v, s, row - s * Lout, col);
+    }
+  }
+  CSTAMP(5);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __restrict__ stages, int nstages,
+                                                             int t_uniform, const long long* tptr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4 wreg[2][WREG];
+  const int z = blockIdx.z, tid = threadIdx.x;
+  const int skey = (nstages < 48 ? nstages : 47) * 2 + (gridDim.z - 1);
+  (void)skey;
+  wfirst(stages[0], z, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, wreg[0]);
+  for (int i = 0; i < nstages; ++i) {
+    const RStage& st = stages[i];
+    const RStage* nx = i + 1 < nstages ? &stages[i + 1] : nullptr;
+    const int b0 = blockIdx.x * st.g.S;
+    if (st.drain) drain_barrier();
+    switch (st.MI * 4 + st.NI) {
+      case 1 * 4 + 1: rc_stage<1, 1>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
+      case 2 * 4 + 1: rc_stage<2, 1>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
+      case 4 * 4 + 1: rc_stage<4, 1>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
+      case 1 * 4 + 2: rc_stage<1, 2>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
+      case 2 * 4 + 2: rc_stage<2, 2>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
+      default: break;
+    }
+    lds_barrier();
+#ifdef TREBI_STAMPS
+    { const int sidx = i; CSTAMP(6); }
+#endif
+  }
+}
+
+bool chain_variant_ok(int MI, int NI) {
+  return (NI == 1 && (MI == 1 || MI == 2 || MI == 4)) || (NI == 2 && (MI == 1 || MI == 2));
+}
+
+hipError_t chain_init_device() {
+  return hipFuncSetAttribute((const void*)resident_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             160 * 1024);
+}
+
+hipError_t launch_chain(const RStage* dev_stages, int nstages, int nz, int nblocks, size_t lds_bytes, int t_uniform,
+                        const long long* t, hipStream_t st) {
+  hipLaunchKernelGGL(resident_chain_kernel, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages, nstages,
+                     t_uniform, t);
+  return hipGetLastError();
+}
+
+}  // namespace trebi

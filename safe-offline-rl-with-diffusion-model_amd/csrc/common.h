@@ -74,13 +74,24 @@ struct ConvLaunch {
   ConvGeo g;                       // both nets of a launch have identical shapes
 };
 
-// One stage of a chained launch: consecutive layers whose workgroups only depend on their own
-// candidates' previous outputs (all output columns in one workgroup) run in ONE launch, separated by
-// a workgroup barrier instead of a kernel boundary.  The table lives in device memory.
-struct ChainStage {
+// One stage of a resident chain: consecutive layers whose workgroups own whole candidates AND all output
+// columns run in ONE launch; a layer's output stays in LDS for the layers that consume it (it is also
+// written to global memory when something outside the chain reads it).  Resident tensors use one canonical
+// LDS layout: per candidate (L + 4) rows of ld = C + 4 floats, two zero halo rows in front and behind.
+// All offsets are in floats from the start of dynamic LDS.  The table lives in device memory.
+struct RStage {
   ConvP p[2];
-  ConvGeo g;
-  int variant;                     // conv_body<MI,NI,VEC>: 0 <1,1,vec>  1 <2,1,vec>  2 <1,1,novec>  3 <2,1,novec>
+  ConvGeo g;                       // tile geometry (the LDS carve in g is not used by the chain)
+  int MI, NI, vec;                 // tile variant; global sources are float4-addressable
+  // primary source: region, rows per candidate, row read by tap 0 of output 0, row of input position 0
+  int srcRes, oSrc, Rb, a0, pr0;
+  int x2Res, o2, Rb2, h2;          // second (1x1) source, read at row s*Rb2 + h2 + lo
+  int resRes, oR, RbR, hR, ldR;    // identity residual, read at row s*RbR + hR + lo
+  int dstRes, oD, RbD, ldD, Ld;    // destination region (canonical layout), Ld positions per candidate
+  int oRed, oRed2, oColp, oTb;     // split-K partials, per-column parameters, time-bias rows
+  int drain;                       // a global source was written by an earlier stage: drain stores first
+  unsigned mLd4;                   // magic multiplier of ldD / 4
+  int proRes, oPro;                // backward stage whose incoming gradient is resident (read-only) at oPro
   int pad_[3];
 };
 
@@ -95,9 +106,10 @@ hipError_t conv_init_device();
 hipError_t launch_conv(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st);
 ConvGeo conv_make_geo(const ConvP& p, const Tile& tl);
 bool conv_vec_ok(const ConvP& p);
-int conv_chain_variant(const Tile& tl, bool vec);      // -1 if the tile shape has no chain variant
-hipError_t launch_conv_chain(const ChainStage* dev_stages, int nstages, int nz, int nblocks, size_t lds_bytes,
-                             int t_uniform, const long long* t, hipStream_t st);
+bool chain_variant_ok(int MI, int NI);
+hipError_t chain_init_device();
+hipError_t launch_chain(const RStage* dev_stages, int nstages, int nz, int nblocks, size_t lds_bytes,
+                        int t_uniform, const long long* t, hipStream_t st);
 
 // Value head (temporal.py:237-238) forward + the seed of the backward.
 struct HeadP {

@@ -32,12 +32,6 @@ extern "C" int trebi_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
-// n / d with a host-computed multiplier (ConvGeo): one mul-hi.
-struct FastDiv {
-  unsigned d, m;
-  __device__ FastDiv(unsigned dd, unsigned mm) : d(dd), m(mm) {}
-  __device__ __forceinline__ unsigned div(unsigned n) const { return m == 0 ? n : __umulhi(n, m); }
-};
 static inline unsigned magic_of(unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
 
 bool conv_vec_ok(const ConvP& q) {
@@ -105,43 +99,6 @@ size_t conv_lds_bytes(const ConvP& p, const Tile& tl) {
   return (size_t)conv_make_geo(p, tl).total * sizeof(float);
 }
 
-// Keep a wave-uniform value in scalar registers: without this the compiler re-reads kernel-argument
-// fields with an s_load + s_waitcnt in front of every use (hundreds of stall cycles per use).
-#define PIN(x) asm volatile("" : "+s"(x))
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-// Sum over a team of 16 lanes (one DPP row) or the whole wave, result in every lane; VALU only.
-__device__ __forceinline__ float team_sum(float v, int ts) {
-  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
-  v += dpp_f<0x141>(v);     // row_half_mirror
-  v += dpp_f<0x140>(v);     // row_mirror
-  if (ts == 64) {           // wave-uniform: the whole wave is one team, every lane is active
-    const int iv = __float_as_int(v);
-    v = __int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16)) +
-        __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
-  }
-  return v;
-}
-__device__ __forceinline__ float hsum(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
-
-// float4 (VEC) or 4 guarded scalars from a row with `left` valid floats starting at sp
-template <bool VEC>
-__device__ __forceinline__ f32x4 load4(const float* sp, int left) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (VEC) {
-    if (left > 0) v = *(const f32x4*)sp;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (e < left) v[e] = sp[e];
-  }
-  return v;
-}
-
 // WB = reduction steps whose weights a wave preloads into registers before anything else.
 template <int MI, int NI, bool VEC>
 __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, float* smem, const int b0, const int n0,
@@ -191,7 +148,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
     for (int u = 0; u < WB; ++u) {
       if (k_begin + u < k_end) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wu + wlane + ni * 64);
+        for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = gld4(wu + wlane + ni * 64);
       }
       wu += wstep;
     }
@@ -205,20 +162,20 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
     if (colt) {
       int n = n0 + tid;
       bool ok = n < N;
-      if (ok && p.bias) c0 = p.bias[n];
-      if (ok && hasgn) { c1 = p.gamma[n]; c2 = p.beta[n]; }
-      if (ok && p.bias2) c3 = p.bias2[n];
+      if (ok && p.bias) c0 = gld(p.bias + n);
+      if (ok && hasgn) { c1 = gld(p.gamma + n); c2 = gld(p.beta + n); }
+      if (ok && p.bias2) c3 = gld(p.bias2 + n);
     }
     auto tb_load = [&](int e) -> float {
       int s = dTN.div(e), c = e - s * TN;
       int n = n0 + c;
       if (s >= nvs || n >= N) return 0.f;
-      long long tt = t_uniform >= 0 ? t_uniform : tptr[b0 + s];
+      long long tt = t_uniform >= 0 ? t_uniform : gldll(tptr + b0 + s);
       tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
-      return p.tbias[(unsigned)tt * (unsigned)N + n];
+      return gld(p.tbias + (unsigned)tt * (unsigned)N + n);
     };
     auto ps_load = [&](int i) -> float {
-      return (i < nvs * GN_GROUPS * 2) ? p.pro_stats[(unsigned)b0 * GN_GROUPS * 2 + i] : 0.f;
+      return (i < nvs * GN_GROUPS * 2) ? gld(p.pro_stats + (unsigned)b0 * GN_GROUPS * 2 + i) : 0.f;
     };
     float tbv[2] = {0.f, 0.f}, psv = 0.f;
     if (hastb) {
@@ -416,7 +373,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
       for (int u = 0; u < WB; ++u) {
         if (base + u < k_end) {
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = *(const f32x4*)(wu + wlane + ni * 64);
+          for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = gld4(wu + wlane + ni * 64);
         }
         wu += wstep;
       }
@@ -502,11 +459,11 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
       dst = pout + orow * ldo + n;
     }
     if (veco) {
-      if (n < N) *(f32x4*)dst = v;
+      if (n < N) gst4(dst, v);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (n + e < N) dst[e] = v[e];
+        if (n + e < N) gst(dst + e, v[e]);
     }
   };
 
@@ -544,8 +501,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
       const float rstd = 1.f / sqrtf(team_sum(sq, ts) * icnt + GN_EPS);
       if (tl == 0 && p.save_stats) {
         float* o = p.save_stats + ((unsigned)(b0 + s) * GN_GROUPS + (n0 / gch + gi)) * 2;
-        o[0] = mean;
-        o[1] = rstd;
+        gst(o, mean);
+        gst(o + 1, rstd);
       }
       for (int e = tl; e < cnt4; e += ts) {
         int lo = dG.div(e), col = gi * gch + 4 * (e - lo * g4), row = s * Lout + lo;
@@ -562,8 +519,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
         }
         if (sy) {
           unsigned so = ((unsigned)b0 * Lout + row) * (unsigned)N + n0 + col;
-          *(f32x4*)&sy[so] = xh;
-          *(f32x4*)&sg[so] = dm * ga;
+          gst4(sy + so, xh);
+          gst4(sg + so, dm * ga);
         }
         finish(m, s, row, col);
       }
@@ -587,42 +544,6 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ConvP& p = L.p[blockIdx.z];
   conv_body<MI, NI, VEC>(p, L.g, smem, blockIdx.x * L.g.S, blockIdx.y * L.g.TN, threadIdx.x, p.t_uniform, p.t);
-}
-
-// Consecutive layers whose workgroups depend only on their own candidates' earlier outputs, in one
-// launch.  Stage i+1 reads what stage i of the SAME workgroup wrote to global memory: the barrier's
-// vmcnt(0) drain makes those stores visible to the compute unit's later loads (each buffer is written
-// before it is first read within a launch, so no stale line can sit in the vector L1).
-__global__ __launch_bounds__(512) void conv_chain_kernel(const ChainStage* __restrict__ stages, int nstages,
-                                                         int t_uniform, const long long* tptr) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  for (int i = 0; i < nstages; ++i) {
-    const ChainStage& st = stages[i];
-    const ConvP& p = st.p[blockIdx.z];
-    const int b0 = blockIdx.x * st.g.S;
-    switch (st.variant) {
-      case 0: conv_body<1, 1, true>(p, st.g, smem, b0, 0, threadIdx.x, t_uniform, tptr); break;
-      case 1: conv_body<2, 1, true>(p, st.g, smem, b0, 0, threadIdx.x, t_uniform, tptr); break;
-      case 2: conv_body<1, 1, false>(p, st.g, smem, b0, 0, threadIdx.x, t_uniform, tptr); break;
-      case 3: conv_body<2, 1, false>(p, st.g, smem, b0, 0, threadIdx.x, t_uniform, tptr); break;
-      default: break;
-    }
-    __syncthreads();
-  }
-}
-
-int conv_chain_variant(const Tile& tl, bool vec) {
-  if (tl.NI != 1) return -1;
-  if (tl.MI == 1) return vec ? 0 : 2;
-  if (tl.MI == 2) return vec ? 1 : 3;
-  return -1;
-}
-
-hipError_t launch_conv_chain(const ChainStage* dev_stages, int nstages, int nz, int nblocks, size_t lds_bytes,
-                             int t_uniform, const long long* t, hipStream_t st) {
-  hipLaunchKernelGGL(conv_chain_kernel, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages, nstages,
-                     t_uniform, t);
-  return hipGetLastError();
 }
 
 template <int MI, int NI>
@@ -654,9 +575,6 @@ hipError_t conv_init_device() {
   TREBI_ATTR(1, 1) TREBI_ATTR(2, 1) TREBI_ATTR(4, 1) TREBI_ATTR(8, 1)
   TREBI_ATTR(1, 2) TREBI_ATTR(2, 2) TREBI_ATTR(4, 2)
 #undef TREBI_ATTR
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)conv_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
   return e;
 }
 

@@ -6,6 +6,18 @@ namespace trebi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Every pointer the kernels receive (inside by-value structs or descriptor tables) points to global
+// memory, but the compiler only sees generic pointers and would emit FLAT loads / stores, which count
+// against lgkmcnt as well as vmcnt -- every wait for LDS data would then also wait for all outstanding
+// global traffic.  These accessors cast to the global address space so that global_load / global_store
+// are emitted.
+#define TREBI_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ float gld(const float* p) { return *(const TREBI_GLOBAL float*)p; }
+__device__ __forceinline__ long long gldll(const long long* p) { return *(const TREBI_GLOBAL long long*)p; }
+__device__ __forceinline__ f32x4 gld4(const float* p) { return *(const TREBI_GLOBAL f32x4*)p; }
+__device__ __forceinline__ void gst(float* p, float v) { *(TREBI_GLOBAL float*)p = v; }
+__device__ __forceinline__ void gst4(float* p, f32x4 v) { *(TREBI_GLOBAL f32x4*)p = v; }
+
 #ifdef TREBI_STAMPS          // diagnostic build only: per-phase cycle stamps of workgroup (0,0,0), wave 0
 extern __device__ unsigned long long g_stamps[32];
 #define STAMP(i)                                                                                  \
@@ -48,6 +60,50 @@ __device__ __forceinline__ void mish_both(float x, float* m, float* dm) {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// n / d with a host-computed multiplier (ConvGeo): one mul-hi.
+struct FastDiv {
+  unsigned d, m;
+  __device__ FastDiv(unsigned dd, unsigned mm) : d(dd), m(mm) {}
+  __device__ __forceinline__ unsigned div(unsigned n) const { return m == 0 ? n : __umulhi(n, m); }
+};
+
+// Keep a wave-uniform value in scalar registers: without this the compiler re-reads kernel-argument
+// fields with an s_load + s_waitcnt in front of every use (hundreds of stall cycles per use).
+#define PIN(x) asm volatile("" : "+s"(x))
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// Sum over a team of 16 lanes (one DPP row) or the whole wave, result in every lane; VALU only.
+__device__ __forceinline__ float team_sum(float v, int ts) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);     // row_half_mirror
+  v += dpp_f<0x140>(v);     // row_mirror
+  if (ts == 64) {           // wave-uniform: the whole wave is one team, every lane is active
+    const int iv = __float_as_int(v);
+    v = __int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16)) +
+        __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  }
+  return v;
+}
+__device__ __forceinline__ float hsum(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
+
+// float4 (VEC) or 4 guarded scalars from a row with `left` valid floats starting at sp
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const float* sp, int left) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (VEC) {
+    if (left > 0) v = gld4(sp);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < left) v[e] = gld(sp + e);
+  }
   return v;
 }
 

@@ -1031,22 +1031,196 @@ typedef std::vector<PlanStep> Plan;
 
 int pow2ceil(int v) { int r = 1; while (r < v) r *= 2; return r; }
 
-// Tile for a chained stage: S candidates per workgroup, ALL output columns in the workgroup.
+// Tile of a resident-chain stage: S candidates per workgroup, ALL output columns in the workgroup.
 bool chain_tile(const Op& op, int S, int max_n, Tile* out) {
-  if (op.kind != 0 || op.Npad > max_n || op.Npad / 16 > 8) return false;
-  if (op.gn && (op.Npad != op.N || op.gnw.gch % 4)) return false;
-  int MI = pow2ceil((S * op.Lout + 15) / 16);
-  if (MI > 2) return false;
-  int NG = op.Npad / 16;
-  int KK = (op.ntaps * op.Cin_p + op.Cin2_p) / 16;
-  int KS = std::max(1, std::min(8 / NG, std::max(1, KK / 4)));
-  *out = Tile{MI, 1, NG, KS, S};
+  if (op.kind != 0 || op.Npad > max_n || op.Npad % 16) return false;
+  const int units = op.Npad / 16;
+  const int NI = units > 8 ? 2 : 1;
+  if (units % NI || units / NI > 8) return false;
+  const int NG = units / NI;
+  const int MI = pow2ceil((S * op.Lout + 15) / 16);
+  if (!chain_variant_ok(MI, NI)) return false;
+  const int KK = (op.ntaps * op.Cin_p + op.Cin2_p) / 16;
+  const int KS = std::max(1, std::min(8 / NG, std::max(1, KK / 4)));
+  const int nteams16 = 4 * NG * KS;
+  if (op.gn) {
+    if (op.Npad != op.N || op.gnw.gch % 4 || op.N % GN_GROUPS) return false;
+    const int ts = (S * GN_GROUPS * 4 <= nteams16) ? 64 : 16;       // all groups sit in the one column tile
+    if (op.Lout * (op.gnw.gch / 4) > 2 * ts) return false;          // a team keeps its group in registers
+  }
+  if (op.pro) {
+    if (op.stride != 1 || op.Lin != op.Lout || op.pro_gn.gch % 4 || op.Cin % 16) return false;
+    const int ts = (S * GN_GROUPS * 4 <= nteams16) ? 64 : 16;
+    if (op.Lin * (op.pro_gn.gch / 4) > 2 * ts || S * GN_GROUPS > 64 * NG * KS / ts) return false;
+  }
+  if (op.osplit && op.osplit % 16) return false;
+  *out = Tile{MI, NI, NG, KS, S};
   return true;
+}
+
+// Try to fold ops [i, ...) into one resident-chain launch; returns the number of ops folded (0: none).
+size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>& o1, size_t i, const Resolver& r0,
+                  const Resolver* r1, int B, int S, int max_n, std::vector<RStage>& tab, Plan& plan) {
+  const int nz = r1 ? 2 : 1;
+  std::vector<Tile> tiles;
+  size_t j = i;
+  static const size_t max_len = getenv("TREBI_CHAIN_MAXLEN") ? (size_t)atoi(getenv("TREBI_CHAIN_MAXLEN")) : 1000;
+  while (j < o0.size() && j - i < max_len) {
+    Tile tl;
+    if (!chain_tile(*o0[j], S, max_n, &tl)) break;
+    tiles.push_back(tl);
+    ++j;
+  }
+  struct Key {
+    int id, coloff, C;
+    bool operator==(const Key& k) const { return id == k.id && coloff == k.coloff && C == k.C; }
+  };
+  auto key_of = [](const BufRef& r, int C) { return Key{r.id, r.coloff, C}; };
+  auto reads = [&](const Op& op, const Key& k) {      // op reads exactly this logical tensor
+    if (op.kind != 0) return false;
+    return key_of(op.src, op.Cin) == k || (op.src2.id != NONE && key_of(op.src2, op.Cin2) == k) ||
+           (op.res.id != NONE && key_of(op.res, op.N) == k);
+  };
+  auto touches = [&](const Op& op, int id) {          // op reads workspace buffer `id` through any view
+    if (op.kind == 1) return op.v_buf == id;
+    return op.src.id == id || op.src2.id == id || op.res.id == id || op.pro_y == id || op.pro_g == id ||
+           op.pro_st == id;
+  };
+  for (; j >= i + 2; --j) {                            // shrink until the chain fits in LDS
+    const size_t n = j - i;
+    std::vector<RStage> run(n);
+    struct Live { Key k; int region; size_t last; int L; };
+    std::vector<Live> live;
+    constexpr int MAXREG = 4;
+    size_t regsz = 0, slabsz = 0, slab2sz = 0, restsz = 0, redsz = 0, red2sz = 0, colsz = 0, tbsz = 0;
+    int nreg = 0;
+    std::vector<int> written;                          // workspace ids stored to global by earlier stages
+    double fl = 0;
+    for (size_t k = 0; k < n; ++k) {
+      const Op& op = *o0[i + k];
+      RStage& st = run[k];
+      st.p[0] = r0.conv(op);
+      if (r1) st.p[1] = r1->conv(*o1[i + k]);
+      const Tile& tl = tiles[k];
+      st.MI = tl.MI; st.NI = tl.NI;
+      st.vec = conv_vec_ok(st.p[0]) && (!r1 || conv_vec_ok(st.p[1]));
+      st.g = conv_make_geo(st.p[0], tl);
+      const ConvGeo& G = st.g;
+      auto find_live = [&](const Key& kk) -> Live* {
+        for (auto& l : live) if (l.k == kk) return &l;
+        return nullptr;
+      };
+      // sources
+      Live* ls = op.src.id >= 0 ? find_live(key_of(op.src, op.Cin)) : nullptr;
+      st.proRes = ls != nullptr && op.pro;            // the prologue copies: the K loop reads the stage slab
+      st.srcRes = ls != nullptr && !op.pro;
+      st.Rb = st.srcRes ? op.Lin + 4 : G.R;
+      st.a0 = st.srcRes ? 2 + op.tap_lo - op.pad : 0;
+      st.pr0 = G.fh;
+      Live* l2 = (op.src2.id >= 0) ? find_live(key_of(op.src2, op.Cin2)) : nullptr;
+      st.x2Res = l2 != nullptr;
+      st.Rb2 = l2 ? op.Lout + 4 : op.Lout;
+      st.h2 = l2 ? 2 : 0;
+      Live* lr = (op.res.id >= 0) ? find_live(key_of(op.res, op.N)) : nullptr;
+      st.resRes = lr != nullptr;
+      st.RbR = lr ? op.Lout + 4 : op.Lout;
+      st.hR = lr ? 2 : 0;
+      st.ldR = lr ? op.N + 4 : G.TNp;
+      const int reg_s = ls ? ls->region : -1, reg_2 = l2 ? l2->region : -1, reg_r = lr ? lr->region : -1;
+      const bool have_s = ls != nullptr, have_2 = l2 != nullptr, have_r = lr != nullptr;
+      if (st.a0 < 0 || (!st.vec && op.pro)) { run.clear(); break; }
+      // global sources written earlier in this chain need the stores drained first
+      auto was_written = [&](int id) { return id >= 0 && std::find(written.begin(), written.end(), id) != written.end(); };
+      st.drain = (!have_s && was_written(op.src.id)) || (op.src2.id != NONE && !have_2 && was_written(op.src2.id)) ||
+                 (op.res.id != NONE && !have_r && was_written(op.res.id)) ||
+                 (op.pro && (was_written(op.pro_y) || was_written(op.pro_g) || was_written(op.pro_st)));
+      // destination
+      const int Cd = op.osplit ? op.osplit : op.N, Ld = op.osplit ? 2 * op.Lout : op.Lout;
+      const Key kd = key_of(op.dst, Cd);
+      size_t last = 0;
+      for (size_t m = k + 1; m < n; ++m)
+        if (reads(*o0[i + m], kd)) last = m;
+      bool need_global = op.dst.id < 0;
+      for (size_t m = 0; m < o0.size() && !need_global; ++m) {
+        if (m >= i && m < j) {
+          if (m > i + k && touches(*o0[m], op.dst.id) && !reads(*o0[m], kd)) need_global = true;
+          continue;
+        }
+        if (m > i + k && touches(*o0[m], op.dst.id)) need_global = true;
+      }
+      st.dstRes = 0;
+      static const bool no_resident = getenv("TREBI_CHAIN_RESIDENT") && atoi(getenv("TREBI_CHAIN_RESIDENT")) == 0;
+      if (last > 0 && op.dst.id >= 0 && op.N == op.Npad && Cd % 16 == 0 && !no_resident) {
+        bool busy[MAXREG] = {false, false, false, false};
+        for (auto& l : live)
+          if (l.last >= k) busy[l.region] = true;       // still read by this or a later stage
+        int reg = -1;
+        for (int q = 0; q < MAXREG; ++q)
+          if (!busy[q]) { reg = q; break; }
+        if (reg >= 0) {
+          live.erase(std::remove_if(live.begin(), live.end(), [&](const Live& l) { return l.region == reg; }),
+                     live.end());
+          live.push_back({kd, reg, last, Ld});
+          st.dstRes = 1;
+          st.oD = reg;                                   // region index for now, offset below
+          st.RbD = Ld + 4; st.ldD = Cd + 4; st.Ld = Ld;
+          st.mLd4 = st.ldD / 4 > 1 ? 0xFFFFFFFFu / (unsigned)(st.ldD / 4) + 1u : 0u;
+          nreg = std::max(nreg, reg + 1);
+          regsz = std::max(regsz, (size_t)S * (Ld + 4) * (Cd + 4));
+        } else {
+          need_global = true;
+        }
+      } else if (last > 0) {
+        need_global = true;
+      }
+      if (!need_global) { st.p[0].out = nullptr; st.p[1].out = nullptr; }
+      if (need_global && op.dst.id >= 0) written.push_back(op.dst.id);
+      for (int id : {op.save_y, op.save_g, op.save_st}) if (id >= 0) written.push_back(id);
+      // remember region indices of the sources (offsets are assigned once the carve is known)
+      st.oSrc = st.srcRes ? reg_s : -1;
+      st.oPro = st.proRes ? reg_s : -1;
+      st.o2 = reg_2;
+      st.oR = reg_r;
+      if (!st.srcRes) slabsz = std::max(slabsz, (size_t)S * G.R * G.ldA);
+      if (op.Cin2_p && !have_2) slab2sz = std::max(slab2sz, (size_t)S * op.Lout * G.ld2);
+      if (op.res.id != NONE && !have_r) restsz = std::max(restsz, (size_t)G.TM * G.TNp);
+      redsz = std::max(redsz, (size_t)G.red1);
+      if (op.Cin2_p) red2sz = std::max(red2sz, (size_t)G.red1);
+      colsz = std::max(colsz, (size_t)4 * G.TN);
+      if (op.tbias) tbsz = std::max(tbsz, (size_t)S * G.TN);
+      fl += op.flops * B * nz;
+    }
+    if (run.empty()) continue;
+    auto r4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
+    regsz = r4(regsz);
+    const size_t oSlab = nreg * regsz, oSlab2 = oSlab + r4(slabsz), oRest = oSlab2 + r4(slab2sz),
+                 oRed = oRest + r4(restsz), oRed2 = oRed + r4(redsz), oCol = oRed2 + r4(red2sz),
+                 oTb = oCol + r4(colsz), total = oTb + r4(tbsz);
+    if (total * sizeof(float) > 160 * 1024) continue;
+    for (auto& st : run) {
+      st.oSrc = st.srcRes ? (int)(st.oSrc * regsz) : (int)oSlab;
+      st.oPro = st.proRes ? (int)(st.oPro * regsz) : 0;
+      st.o2 = st.x2Res ? (int)(st.o2 * regsz) : (int)oSlab2;
+      st.oR = st.resRes ? (int)(st.oR * regsz) : (int)oRest;
+      st.oD = st.dstRes ? (int)(st.oD * regsz) : 0;
+      st.oRed = (int)oRed; st.oRed2 = (int)oRed2; st.oColp = (int)oCol; st.oTb = (int)oTb;
+    }
+    PlanStep ps;
+    ps.kind = 2; ps.nz = nz;
+    ps.chain_off = (int)tab.size(); ps.chain_n = (int)n;
+    ps.nblocks = (B + S - 1) / S;
+    ps.chain_lds = total * sizeof(float); ps.flops = fl;
+    ps.name = "chain[" + std::to_string(n) + "] S" + std::to_string(S) + " " + o0[i]->name + " .. " + o0[j - 1]->name;
+    tab.insert(tab.end(), run.begin(), run.end());
+    plan.push_back(ps);
+    return n;
+  }
+  return 0;
 }
 
 int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vector<const std::vector<Op>*>& lists1,
                const Resolver& r0, const Resolver* r1, int B, bool want_grad, int chain_S, int chain_max_n,
-               std::vector<ChainStage>& tab, Plan& plan) {
+               std::vector<RStage>& tab, Plan& plan) {
   const int nz = r1 ? 2 : 1;
   std::vector<const Op*> o0, o1;
   for (auto* l : lists0) for (auto& op : *l) o0.push_back(&op);
@@ -1064,39 +1238,9 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
       ++i;
       continue;
     }
-    // try to start a chain here
-    size_t j = i;
-    std::vector<ChainStage> run;
-    size_t lds = 0;
-    double fl = 0;
-    while (chain_S > 0 && j < o0.size()) {
-      Tile tl;
-      if (!chain_tile(*o0[j], chain_S, chain_max_n, &tl)) break;
-      ChainStage cs{};
-      cs.p[0] = r0.conv(*o0[j]);
-      if (r1) cs.p[1] = r1->conv(*o1[j]);
-      bool vec = conv_vec_ok(cs.p[0]) && (!r1 || conv_vec_ok(cs.p[1]));
-      cs.variant = conv_chain_variant(tl, vec);
-      if (cs.variant < 0 || (o0[j]->pro && !vec)) break;
-      cs.g = conv_make_geo(cs.p[0], tl);
-      size_t need = (size_t)cs.g.total * sizeof(float);
-      if (need > 160 * 1024) break;
-      lds = std::max(lds, need);
-      fl += o0[j]->flops * B * nz;
-      run.push_back(cs);
-      ++j;
-    }
-    if (run.size() >= 2) {
-      PlanStep st;
-      st.kind = 2; st.nz = nz;
-      st.chain_off = (int)tab.size(); st.chain_n = (int)run.size();
-      st.nblocks = (B + chain_S - 1) / chain_S;
-      st.chain_lds = lds; st.flops = fl;
-      st.name = "chain[" + std::to_string(run.size()) + "] " + o0[i]->name + " .. " + o0[j - 1]->name;
-      tab.insert(tab.end(), run.begin(), run.end());
-      plan.push_back(st);
-      i = j;
-      continue;
+    if (chain_S > 0) {
+      size_t n = plan_chain(o0, o1, i, r0, r1, B, chain_S, chain_max_n, tab, plan);
+      if (n) { i += n; continue; }
     }
     PlanStep st;
     st.kind = 0; st.nz = nz;
@@ -1123,7 +1267,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
   return 0;
 }
 
-int exec_plan(const Plan& plan, const ChainStage* dev_tab, int t_uniform, const long long* tptr, hipStream_t st,
+int exec_plan(const Plan& plan, const RStage* dev_tab, int t_uniform, const long long* tptr, hipStream_t st,
               GemmProfile* prof) {
   for (const PlanStep& ps : plan) {
     if (ps.kind == 1) {
@@ -1143,7 +1287,7 @@ int exec_plan(const Plan& plan, const ChainStage* dev_tab, int t_uniform, const 
       HIPCHK(hipEventRecord(prof->ev[prof->used].first, st));
     }
     if (ps.kind == 2) {
-      HIPCHK(launch_conv_chain(dev_tab + ps.chain_off, ps.chain_n, ps.nz, ps.nblocks, ps.chain_lds, t_uniform, tptr, st));
+      HIPCHK(launch_chain(dev_tab + ps.chain_off, ps.chain_n, ps.nz, ps.nblocks, ps.chain_lds, t_uniform, tptr, st));
     } else {
       ConvLaunch L = ps.L;
       for (int z = 0; z < ps.nz; ++z) { L.p[z].t = tptr; L.p[z].t_uniform = t_uniform; }
@@ -1189,6 +1333,7 @@ extern "C" int trebi_ctx_create(int device, trebi_ctx** out) {
     return fail(TREBI_UNSUPPORTED_CONFIG, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
                 prop.gcnArchName);
   HIPCHK(conv_init_device());
+  HIPCHK(chain_init_device());
   *out = new trebi_ctx{device};
   return 0;
 }
@@ -1398,7 +1543,7 @@ struct trebi_sampler {
   // launch plans (resolved once per set of caller pointers) and the device table of chained stages
   std::vector<Plan> vf_grad, vf_nograd;   // one entry (both nets in one launch / a single net) or two
   Plan unet_plan;
-  ChainStage* dev_tab = nullptr;
+  RStage* dev_tab = nullptr;
   size_t dev_tab_cap = 0;
   const void* plan_key[3] = {};
   bool plans_valid = false;
@@ -1481,7 +1626,7 @@ static int ensure_plans(trebi_sampler* s, float* x, float* values, float* costs)
   const char* e_maxn = getenv("TREBI_CHAIN_MAXN");
   const int chain_S = (e_chain && atoi(e_chain) == 0) || B > 1024 ? 0 : 1;
   const int chain_max_n = e_maxn ? atoi(e_maxn) : 64;   // measured best at 64 candidates (wider layers want more workgroups)
-  std::vector<ChainStage> tab;
+  std::vector<RStage> tab;
   s->vf_grad.clear(); s->vf_nograd.clear(); s->unet_plan.clear();
   Binding bu;
   bu.x = x; bu.ldx = D; bu.out = s->x0; bu.ldo = D; bu.ws = s->ws_u;
@@ -1517,9 +1662,9 @@ static int ensure_plans(trebi_sampler* s, float* x, float* values, float* costs)
     if (s->dev_tab) (void)hipFree(s->dev_tab);
     s->dev_tab = nullptr;
     s->dev_tab_cap = tab.size() + 64;
-    HIPCHK(hipMalloc((void**)&s->dev_tab, s->dev_tab_cap * sizeof(ChainStage)));
+    HIPCHK(hipMalloc((void**)&s->dev_tab, s->dev_tab_cap * sizeof(RStage)));
   }
-  if (!tab.empty()) HIPCHK(hipMemcpy(s->dev_tab, tab.data(), tab.size() * sizeof(ChainStage), hipMemcpyHostToDevice));
+  if (!tab.empty()) HIPCHK(hipMemcpy(s->dev_tab, tab.data(), tab.size() * sizeof(RStage), hipMemcpyHostToDevice));
   memcpy(s->plan_key, key, sizeof key);
   s->plans_valid = true;
   return 0;
