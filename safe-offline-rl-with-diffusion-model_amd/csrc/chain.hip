@@ -20,14 +20,14 @@
 namespace trebi {
 
 #ifdef TREBI_STAMPS          // diagnostic build: cycle stamps of workgroup (0,0,0) per (launch shape, stage, phase)
-__device__ unsigned long long g_cstamps[96 * 48 * 8];
+__device__ unsigned long long g_cstamps[96 * 48 * 16];
 extern "C" int trebi_debug_read_cstamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamps), sizeof(g_cstamps));
 }
 #define CSTAMP(ph)                                                                                 \
   do {                                                                                             \
     if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)                                    \
-      g_cstamps[((size_t)skey * 48 + sidx) * 8 + (ph)] = __builtin_amdgcn_s_memtime();             \
+      g_cstamps[((size_t)skey * 48 + sidx) * 16 + (ph)] = __builtin_amdgcn_s_memtime();             \
   } while (0)
 #else
 #define CSTAMP(ph)
@@ -100,6 +100,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
   PIN(px); PIN(pw); PIN(pout); PIN(ldx); PIN(Cin); PIN(Lin); PIN(Lout); PIN(stride); PIN(B); PIN(N); PIN(Npad);
   PIN(S); PIN(NG); PIN(KS); PIN(nthr); PIN(TM); PIN(TN); PIN(TNp); PIN(R); PIN(ldA); PIN(ld2);
   PIN(cbpt); PIN(KK1); PIN(KK); PIN(chunk); PIN(nv); PIN(fh); PIN(Rb); PIN(a0); PIN(Rb2); PIN(h2);
+  CSTAMP(7);
   const bool has2 = p.Cin2_p != 0, haspro = p.pro != 0, hasres = p.res != nullptr || st.resRes,
              hastb = p.tbias != nullptr, hasgn = p.gn != 0;
   const bool vec = st.vec != 0;
@@ -152,9 +153,19 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
       }
     }
   }
+  // per-column parameters and time-bias rows: requested now, parked in registers, written to LDS after the K
+  // loop (consuming a load here would also wait for the previous stage's stores: vmcnt retires in order)
+  float c0 = 0.f, c1 = 1.f, c2 = 0.f, c3 = 0.f;
+  float tbv[2] = {0.f, 0.f};
+  const bool colt = active && tid < TN;
+  auto tb_load = [&](int e) -> float {
+    int s = dTN.div(e), c = e - s * TN;
+    if (s >= nvs || c >= N) return 0.f;
+    long long tt = t_uniform >= 0 ? t_uniform : gldll(tptr + b0 + s);
+    tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
+    return gld(p.tbias + (unsigned)tt * (unsigned)N + c);
+  };
   if (active) {
-    float c0 = 0.f, c1 = 1.f, c2 = 0.f, c3 = 0.f;
-    const bool colt = tid < TN;
     if (colt) {
       const int n = tid;
       const bool ok = n < N;
@@ -162,14 +173,6 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
       if (ok && hasgn) { c1 = gld(p.gamma + n); c2 = gld(p.beta + n); }
       if (ok && p.bias2) c3 = gld(p.bias2 + n);
     }
-    auto tb_load = [&](int e) -> float {
-      int s = dTN.div(e), c = e - s * TN;
-      if (s >= nvs || c >= N) return 0.f;
-      long long tt = t_uniform >= 0 ? t_uniform : gldll(tptr + b0 + s);
-      tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
-      return gld(p.tbias + (unsigned)tt * (unsigned)N + c);
-    };
-    float tbv[2] = {0.f, 0.f};
     if (hastb) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -253,18 +256,6 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
         int row = s * st.RbD + (k < 2 ? k : st.Ld + k);
         *(f32x4*)&dreg[row * st.ldD + 4 * c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-    }
-    if (colt) {
-      colp[tid] = c0;
-      colp[TN + tid] = c1;
-      colp[2 * TN + tid] = c2;
-      colp[3 * TN + tid] = c3;
-    }
-    if (hastb) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        if (tid + u * nthr < S * TN) tbrow[tid + u * nthr] = tbv[u];
-      for (int e = tid + 2 * nthr; e < S * TN; e += nthr) tbrow[e] = tb_load(e);
     }
   }
   CSTAMP(1);
@@ -359,6 +350,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
         }
       }
     };
+    CSTAMP(8);
     for (int kb = k_begin; kb < k_end; kb += 2 * WH) {
       const bool more = kb + WH < k_end;
       if (more) wload(wreg[1], pw, wstep, wlane, NI, kb + WH, k_end);
@@ -368,6 +360,18 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
         compute(wreg[1], kb + WH);
       }
     }
+  }
+  if (colt) {
+    colp[tid] = c0;
+    colp[TN + tid] = c1;
+    colp[2 * TN + tid] = c2;
+    colp[3 * TN + tid] = c3;
+  }
+  if (hastb && active) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + u * nthr < S * TN) tbrow[tid + u * nthr] = tbv[u];
+    for (int e = tid + 2 * nthr; e < S * TN; e += nthr) tbrow[e] = tb_load(e);
   }
   CSTAMP(3);
   // the next stage's first weight block travels while this stage reduces and normalises
@@ -461,7 +465,9 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
           sum += hsum(a);
         }
       }
+      CSTAMP(9);
       const float mean = team_sum(sum, ts) * icnt;
+      CSTAMP(10);
       float sq = 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -470,6 +476,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
           sq += hsum(d * d);
         }
       const float rstd = 1.f / sqrtf(team_sum(sq, ts) * icnt + GN_EPS);
+      CSTAMP(11);
       if (tl == 0 && p.save_stats) {
         float* o = p.save_stats + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2;
         gst(o, mean);
@@ -490,6 +497,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
             m[q] = a;
             dm[q] = b;
           }
+          CSTAMP(12 + j);
           if (sy) {
             unsigned so = ((unsigned)b0 * Lout + s * Lout + lo_[j]) * (unsigned)N + col;
             gst4(sy + so, xh);

@@ -18,11 +18,11 @@ for _ in range(2):
     diff.sample_raw((B, bench.H, bench.OBS + bench.ACT), {0: obs[None].expand(B, -1)}, sample_fn=fn, cost_threshold=0.1, **kw)
 torch.cuda.synchronize()
 lib = _lib.lib()
-n = 96 * 48 * 8
+n = 96 * 48 * 16
 buf = (C.c_uint64 * n)()
 lib.trebi_debug_read_cstamps.argtypes = [C.POINTER(C.c_uint64)]
 lib.trebi_debug_read_cstamps(buf)
-a = np.frombuffer(buf, dtype=np.uint64).reshape(96, 48, 8).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(96, 48, 16).astype(np.int64)
 print('phases: A(stage/loads) bar+prologue kloop partials+bar epilogue endbar | total')
 for key in range(96):
     if a[key].any():
@@ -31,4 +31,4 @@ for key in range(96):
         for i in range(ns):
             s = a[key, i]
             d = [s[k + 1] - s[k] for k in range(6)]
-            print(f'{i:3d}', ' '.join(f'{x:6d}' for x in d), '|', s[6] - s[0])
+            print(f'{i:3d}', ' '.join(f'{x:6d}' for x in d), '|', s[6] - s[0], '| pins', s[7] - s[0], '| k-setup', s[8] - s[2], '| epi: partial-sum', s[9] - s[4], 'mean', s[10] - s[9], 'rstd', s[11] - s[10], 'mish0', s[12] - s[11], 'fin0+mish1', s[13] - s[12], 'fin1', s[5] - s[13])
