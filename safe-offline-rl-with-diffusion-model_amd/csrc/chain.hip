@@ -65,22 +65,49 @@ __device__ __forceinline__ void wload(f32x4 (&w)[WREG], const float* pw, unsigne
 }
 
 // First weight block of a stage, for the wave `wave` (any stage: used for stage 0 and as the prefetch).
+// Direct stages keep a block of n < WH steps in the LAST n register slots (see the K loop).
 __device__ __forceinline__ void wfirst(const RStage& st, int z, int wave, int lane, f32x4 (&w)[WREG]) {
   const int NG = st.g.NG, KS = st.g.KS, NI = st.NI;
   if (wave >= NG * KS) return;
   const int ks = FastDiv(NG, st.g.mNG).div(wave), ng = wave - ks * NG;
   const int Npad = st.p[z].Npad;
+  const unsigned wlane = (unsigned)(((lane >> 4) * Npad + ng * NI * 16 + (lane & 15)) * 4);
+  const unsigned wstep = (unsigned)Npad * 16u;
+  if (st.direct) {
+    const int WH = WREG / NI;
+    const int lim = st.g.KK1 > 0 ? st.g.KK1 : st.g.KK;
+    const int n = lim < WH ? lim : WH;
+    const float* wu = st.p[z].w + wlane;
+    if (NI == 1) {
+#pragma unroll
+      for (int u = 0; u < WREG; ++u)
+        if (u >= WREG - n) { w[u] = gld4(wu); wu += wstep; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < WREG / 2; ++u)
+        if (u >= WREG / 2 - n) { w[2 * u] = gld4(wu); w[2 * u + 1] = gld4(wu + 64); wu += wstep; }
+    }
+    return;
+  }
   const int kb = ks * st.g.chunk;
   const int ke = kb + st.g.chunk < st.g.KK ? kb + st.g.chunk : st.g.KK;
-  const unsigned wlane = (unsigned)(((lane >> 4) * Npad + ng * NI * 16 + (lane & 15)) * 4);
-  wload(w, st.p[z].w, (unsigned)Npad * 16u, wlane, NI, kb, ke);
+  wload(w, st.p[z].w, wstep, wlane, NI, kb, ke);
+}
+
+// Sum over aligned groups of `lanes` (4, 8 or 16) lanes of each 16-lane row; VALU only.
+__device__ __forceinline__ float row_sum(float v, int lanes) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  if (lanes >= 8) v += dpp_f<0x141>(v);      // row_half_mirror
+  if (lanes >= 16) v += dpp_f<0x140>(v);     // row_mirror
+  return v;
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* sp, int left, bool vec) {
   return vec ? load4<true>(sp, left) : load4<false>(sp, left);
 }
 
-template <int MI, int NI>
+template <int MI, int NI, bool DIRECT>
 __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, const int z, float* smem, const int tid,
                                          const int b0, int t_uniform, const long long* tptr,
                                          f32x4 (&wreg)[2][WREG], int skey, int sidx) {
@@ -118,8 +145,10 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
 
   const int g = lane >> 4, lr = lane & 15;
   const int ks = FastDiv(NG, G.mNG).div(wave), ng = wave - ks * NG;
-  const int k_begin = active ? ks * chunk : 0;
-  const int k_end = active ? ((k_begin + chunk < KK) ? k_begin + chunk : KK) : 0;
+  // split-K stages: wave = (K split ks, column group ng); direct stages: wave = (row tile ks, column group ng)
+  const int k_begin = (active && !DIRECT) ? ks * chunk : 0;
+  const int k_end = active ? (DIRECT ? KK : ((k_begin + chunk < KK) ? k_begin + chunk : KK)) : 0;
+  const int rowbase = DIRECT ? ks * 16 : 0;
   const unsigned wlane = (unsigned)((g * Npad + ng * NI * 16 + lr) * 4);
   const unsigned wstep = (unsigned)Npad * 16u;
 
@@ -154,10 +183,14 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
     }
   }
   // per-column parameters and time-bias rows: requested now, parked in registers, written to LDS after the K
-  // loop (consuming a load here would also wait for the previous stage's stores: vmcnt retires in order)
+  // loop (consuming a load here would also wait for the previous stage's stores: vmcnt retires in order).
+  // Direct stages: a lane's accumulators all sit in one column per sub-tile, so the parameters simply stay
+  // in that lane's registers.
   float c0 = 0.f, c1 = 1.f, c2 = 0.f, c3 = 0.f;
   float tbv[2] = {0.f, 0.f};
-  const bool colt = active && tid < TN;
+  float dbias[NI], dgam[NI], dbet[NI], dbi2[NI], dtb[NI];
+  const int sw = DIRECT ? (int)dLout.div(rowbase) : 0;        // direct: the candidate of this wave's 16 rows
+  const bool colt = !DIRECT && active && tid < TN;
   auto tb_load = [&](int e) -> float {
     int s = dTN.div(e), c = e - s * TN;
     if (s >= nvs || c >= N) return 0.f;
@@ -166,6 +199,23 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
     return gld(p.tbias + (unsigned)tt * (unsigned)N + c);
   };
   if (active) {
+    if (DIRECT) {
+      long long tt = 0;
+      if (hastb) {
+        tt = t_uniform >= 0 ? t_uniform : (sw < nvs ? gldll(tptr + b0 + sw) : 0);
+        tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = (ng * NI + ni) * 16 + lr;
+        const bool ok = n < N;
+        dbias[ni] = (ok && p.bias) ? gld(p.bias + n) : 0.f;
+        dgam[ni] = (ok && hasgn) ? gld(p.gamma + n) : 1.f;
+        dbet[ni] = (ok && hasgn) ? gld(p.beta + n) : 0.f;
+        dbi2[ni] = (ok && p.bias2) ? gld(p.bias2 + n) : 0.f;
+        dtb[ni] = (ok && hastb) ? gld(p.tbias + (unsigned)tt * (unsigned)N + n) : 0.f;
+      }
+    }
     if (colt) {
       const int n = tid;
       const bool ok = n < N;
@@ -173,7 +223,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
       if (ok && hasgn) { c1 = gld(p.gamma + n); c2 = gld(p.beta + n); }
       if (ok && p.bias2) c3 = gld(p.bias2 + n);
     }
-    if (hastb) {
+    if (hastb && !DIRECT) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         if (tid + u * nthr < S * TN) tbv[u] = tb_load(tid + u * nthr);
@@ -298,11 +348,104 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
       acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-  if (active) {
+  if (DIRECT && active) {
+    // One 16 x (16*NI) tile per wave over the whole reduction, in blocks of up to WH steps that never
+    // straddle the two sources.  A block with n steps uses the LAST n register slots and enters a fully
+    // unrolled step sequence at slot WH-n (one branch per block, none per step): all A operands of the
+    // block are requested from LDS before its first MFMA -- with one or two waves per SIMD nothing else
+    // hides the LDS latency -- and the weights of the next block travel meanwhile.
+    const int r = rowbase + lr;
+    const int s = dLout.div(r), lo = r - s * Lout;
+    const int offA = st.oSrc + (s * Rb + lo * stride + a0) * ldA + 4 * g;
+    const int off2 = st.o2 + (s * Rb2 + h2 + lo) * ld2 + 4 * g;
+    const int KK2 = KK - KK1;
+    const int nb1 = (KK1 + WH - 1) / WH, nb = nb1 + (KK2 + WH - 1) / WH;
+    const FastDiv dCb(cbpt, G.mCbpt);
+    // block i: [kb, kb+n) of source 1 (i < nb1) or of source 2
+    auto blk_kb = [&](int i) { return i < nb1 ? i * WH : KK1 + (i - nb1) * WH; };
+    auto blk_n = [&](int i) {
+      const int kb = blk_kb(i), ke = i < nb1 ? KK1 : KK;
+      return ke - kb < WH ? ke - kb : WH;
+    };
+    // weights of block i into the last n slots of w
+    auto wblk = [&](f32x4 (&w)[WREG], int i) {
+      const int kb = blk_kb(i), n = blk_n(i);
+      const float* wu = pw + (size_t)kb * wstep + wlane;
+#pragma unroll
+      for (int u = 0; u < WH; ++u) {
+        if (u >= WH - n) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) w[u * NI + ni] = gld4(wu + ni * 64);
+          wu += wstep;
+        }
+      }
+    };
+    auto run = [&](const f32x4 (&w)[WREG], int i) {
+      const int kb = blk_kb(i), n = blk_n(i);
+      f32x4 a[WH];
+      if (i < nb1) {
+        int tau = dCb.div(kb);
+        int cb = kb - tau * cbpt;
+        int aoff = offA + tau * ldA + cb * 16;
+#pragma unroll
+        for (int u = 0; u < WH; ++u) {
+          if (u >= WH - n) {
+            a[u] = *(const f32x4*)&smem[aoff];
+            aoff += 16;
+            if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
+          }
+        }
+#define TREBI_STEP(u, ACC)                                                                              \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)       \
+      ACC[0][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], w[(u) * NI + ni][j], ACC[0][ni], 0, 0, 0);
+        switch (WH - n) {
+          case 0: if (WH > 0) { TREBI_STEP(0, acc) } [[fallthrough]];
+          case 1: if (WH > 1) { TREBI_STEP(1, acc) } [[fallthrough]];
+          case 2: if (WH > 2) { TREBI_STEP(2, acc) } [[fallthrough]];
+          case 3: if (WH > 3) { TREBI_STEP(3, acc) } [[fallthrough]];
+          case 4: if (WH > 4) { TREBI_STEP(4 % WH, acc) } [[fallthrough]];
+          case 5: if (WH > 5) { TREBI_STEP(5 % WH, acc) } [[fallthrough]];
+          case 6: if (WH > 6) { TREBI_STEP(6 % WH, acc) } [[fallthrough]];
+          case 7: if (WH > 7) { TREBI_STEP(7 % WH, acc) } [[fallthrough]];
+          default: break;
+        }
+      } else {
+        int aoff = off2 + (kb - KK1) * 16;
+#pragma unroll
+        for (int u = 0; u < WH; ++u) {
+          if (u >= WH - n) {
+            a[u] = *(const f32x4*)&smem[aoff];
+            aoff += 16;
+          }
+        }
+        switch (WH - n) {
+          case 0: if (WH > 0) { TREBI_STEP(0, acc2) } [[fallthrough]];
+          case 1: if (WH > 1) { TREBI_STEP(1, acc2) } [[fallthrough]];
+          case 2: if (WH > 2) { TREBI_STEP(2, acc2) } [[fallthrough]];
+          case 3: if (WH > 3) { TREBI_STEP(3, acc2) } [[fallthrough]];
+          case 4: if (WH > 4) { TREBI_STEP(4 % WH, acc2) } [[fallthrough]];
+          case 5: if (WH > 5) { TREBI_STEP(5 % WH, acc2) } [[fallthrough]];
+          case 6: if (WH > 6) { TREBI_STEP(6 % WH, acc2) } [[fallthrough]];
+          case 7: if (WH > 7) { TREBI_STEP(7 % WH, acc2) } [[fallthrough]];
+          default: break;
+        }
+#undef TREBI_STEP
+      }
+    };
+    for (int i = 0; i < nb; i += 2) {
+      if (i + 1 < nb) wblk(wreg[1], i + 1);
+      run(wreg[0], i);
+      if (i + 1 < nb) {
+        if (i + 2 < nb) wblk(wreg[0], i + 2);
+        run(wreg[1], i + 1);
+      }
+    }
+  }
+  if (!DIRECT && active) {
     int rowA[MI], row2[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      int r = mi * 16 + lr;
+      int r = rowbase + mi * 16 + lr;
       int s = dLout.div(r), lo = r - s * Lout;
       bool ok = s < S;
       rowA[mi] = ok ? (s * Rb + lo * stride + a0) * ldA + 4 * g : 4 * g;
@@ -367,7 +510,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
     colp[2 * TN + tid] = c2;
     colp[3 * TN + tid] = c3;
   }
-  if (hastb && active) {
+  if (hastb && active && !DIRECT) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       if (tid + u * nthr < S * TN) tbrow[tid + u * nthr] = tbv[u];
@@ -377,8 +520,9 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
   // the next stage's first weight block travels while this stage reduces and normalises
   if (nx) wfirst(*nx, z, wave, lane, wreg[0]);
 
-  // ---- split-K partials -> LDS.  C/D layout: col = lane&15, row = 4*(lane>>4) + reg -------
   const int kstride = TM * TNp;
+  if (!DIRECT) {
+  // ---- split-K partials -> LDS.  C/D layout: col = lane&15, row = 4*(lane>>4) + reg -------
   if (active) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -391,8 +535,137 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
           if (has2) red2[o] = acc2[mi][ni][q];
         }
   }
-  lds_barrier();
+    lds_barrier();
+  }
   CSTAMP(4);
+  if constexpr (DIRECT) {
+    // ---- direct epilogue: this wave's 16 x (16*NI) tile is final; everything happens in registers ----
+    // MFMA C layout: lane holds column lr of each sub-tile, rows 4*g + q.  The 16 rows belong to ONE
+    // candidate (Lout is 16 or 32, checked on the host); with Lout == 32 the other half of the candidate is
+    // the wave with the neighbouring row tile, and the two exchange (mean, M2) through LDS once.
+    const FastDiv dOs(p.osplit > 0 ? p.osplit : 1, G.mOs);
+    const int osplit = p.osplit;
+    const unsigned ldo = p.ldo;
+    const int RbR = st.RbR, hR = st.hR, ldR = st.ldR, RbD = st.RbD, ldD = st.ldD;
+    const bool dstRes = st.dstRes != 0;
+    const int lo0 = rowbase - sw * Lout + 4 * g;
+    const bool live = active && sw < nvs;
+    const bool two = Lout > 16;
+    float v[NI][4], ml[NI], m2[NI];
+    int cols[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      cols[ni] = (ng * NI + ni) * 16 + lr;
+      ml[ni] = 0.f;
+      m2[ni] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[ni][q] = acc[0][ni][q] + dbias[ni];
+    }
+    float* xch = red;                                  // [wave][NI][16][2]
+    const int gch = p.gch;
+    if (hasgn && active) {
+      const int rl = gch < 16 ? gch : 16;              // lanes of a 16-lane row that share a group
+      const bool both = NI == 2 && gch > 16;           // the group spans both sub-tiles of the wave
+      const float inl = 1.f / (float)(16 * gch);
+      float s1[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) s1[ni] = (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
+      if (both) s1[0] = s1[NI - 1] = s1[0] + s1[NI - 1];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float t = row_sum(s1[ni], rl);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        ml[ni] = t * inl;
+      }
+      float s2[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        s2[ni] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float d = v[ni][q] - ml[ni];
+          s2[ni] += d * d;
+        }
+      }
+      if (both) s2[0] = s2[NI - 1] = s2[0] + s2[NI - 1];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float t = row_sum(s2[ni], rl);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        m2[ni] = t;
+        if (two && g == 0) {
+          float* o = xch + ((wave * NI + ni) * 16 + lr) * 2;
+          o[0] = ml[ni];
+          o[1] = t;
+        }
+      }
+    }
+    if (hasgn && two) lds_barrier();
+    if (live) {
+      const FastDiv dG(G.gch4, G.mGch4);
+      float* sy = p.save_y;
+      float* sg = p.save_g;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = cols[ni];
+        int ph = 0, ch = col;
+        if (osplit > 0) {
+          ph = dOs.div(col);
+          ch = col - ph * osplit;
+        }
+        float mean = ml[ni], rstd = 0.f;
+        if (hasgn) {
+          float M2 = m2[ni], cnt = (float)(16 * gch);
+          if (two) {
+            const int pwv = (ks & 1) ? wave - NG : wave + NG;
+            const float* o = xch + ((pwv * NI + ni) * 16 + lr) * 2;
+            const float mp = o[0], m2p = o[1];
+            const float dlt = mean - mp;
+            M2 = M2 + m2p + dlt * dlt * (0.5f * cnt);
+            mean = 0.5f * (mean + mp);
+            cnt *= 2.f;
+          }
+          rstd = __frsqrt_rn(M2 / cnt + GN_EPS);
+          const int gi = dG.div(col >> 2);
+          if (p.save_stats && g == 0 && (col & (gch - 1)) == 0 && (!two || (ks & 1) == 0)) {
+            float* o = p.save_stats + ((unsigned)(b0 + sw) * GN_GROUPS + gi) * 2;
+            gst(o, mean);
+            gst(o + 1, rstd);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int lo = lo0 + q;
+          float val = v[ni][q];
+          if (hasgn) {
+            const float xh = (val - mean) * rstd;
+            float a, b;
+            mish_both(xh * dgam[ni] + dbet[ni], &a, &b);
+            if (sy && col < N) {
+              const unsigned so = ((unsigned)(b0 + sw) * Lout + lo) * (unsigned)N + col;
+              gst(sy + so, xh);
+              gst(sg + so, b * dgam[ni]);
+            }
+            val = a;
+          }
+          val += dtb[ni];
+          if (has2) val += acc2[0][ni][q] + dbi2[ni];
+          if (hasres) val += resb[(sw * RbR + hR + lo) * ldR + col];
+          const int pos = osplit > 0 ? 2 * lo + ph : lo;
+          if (dstRes) dreg[(sw * RbD + 2 + pos) * ldD + ch] = val;
+          if (pout && col < N) {
+            const unsigned orow = (unsigned)(b0 + sw) * Lout + lo;
+            float* dst = osplit > 0 ? pout + (orow * 2 + ph) * ldo + ch : pout + orow * ldo + col;
+            gst(dst, val);
+          }
+        }
+      }
+    }
+    CSTAMP(5);
+    return;
+  }
   if (!active) return;
 
   const FastDiv dOs(p.osplit > 0 ? p.osplit : 1, G.mOs);
@@ -535,14 +808,21 @@ __global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __res
     const RStage* nx = i + 1 < nstages ? &stages[i + 1] : nullptr;
     const int b0 = blockIdx.x * st.g.S;
     if (st.drain) drain_barrier();
-    switch (st.MI * 4 + st.NI) {
-      case 1 * 4 + 1: rc_stage<1, 1>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
-      case 2 * 4 + 1: rc_stage<2, 1>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
-      case 4 * 4 + 1: rc_stage<4, 1>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
-      case 1 * 4 + 2: rc_stage<1, 2>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
-      case 2 * 4 + 2: rc_stage<2, 2>(st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i); break;
-      default: break;
+#define RC_ARGS st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i
+    if (st.direct) {
+      if (st.NI == 1) rc_stage<1, 1, true>(RC_ARGS);
+      else rc_stage<1, 2, true>(RC_ARGS);
+    } else {
+      switch (st.MI * 4 + st.NI) {
+        case 1 * 4 + 1: rc_stage<1, 1, false>(RC_ARGS); break;
+        case 2 * 4 + 1: rc_stage<2, 1, false>(RC_ARGS); break;
+        case 4 * 4 + 1: rc_stage<4, 1, false>(RC_ARGS); break;
+        case 1 * 4 + 2: rc_stage<1, 2, false>(RC_ARGS); break;
+        case 2 * 4 + 2: rc_stage<2, 2, false>(RC_ARGS); break;
+        default: break;
+      }
     }
+#undef RC_ARGS
     lds_barrier();
 #ifdef TREBI_STAMPS
     { const int sidx = i; CSTAMP(6); }

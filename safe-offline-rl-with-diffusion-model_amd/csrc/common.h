@@ -92,7 +92,8 @@ struct RStage {
   int drain;                       // a global source was written by an earlier stage: drain stores first
   unsigned mLd4;                   // magic multiplier of ldD / 4
   int proRes, oPro;                // backward stage whose incoming gradient is resident (read-only) at oPro
-  int pad_[3];
+  int direct;                      // no split-K: a wave owns a 16-row x (16*NI)-column tile and finishes it in registers
+  int pad_[2];
 };
 
 struct Tile {

@@ -1032,15 +1032,40 @@ typedef std::vector<PlanStep> Plan;
 int pow2ceil(int v) { int r = 1; while (r < v) r *= 2; return r; }
 
 // Tile of a resident-chain stage: S candidates per workgroup, ALL output columns in the workgroup.
-bool chain_tile(const Op& op, int S, int max_n, Tile* out) {
+// Preferred: the direct form (no split-K; a wave owns 16 rows x 16*NI columns and finishes them in
+// registers), possible when a wave's 16 rows lie in one candidate and the whole tile fits 8 waves.
+bool chain_tile(const Op& op, int S, int max_n, Tile* out, bool* direct) {
   if (op.kind != 0 || op.Npad > max_n || op.Npad % 16) return false;
   const int units = op.Npad / 16;
   const int NI = units > 8 ? 2 : 1;
   if (units % NI || units / NI > 8) return false;
   const int NG = units / NI;
+  const int KK = (op.ntaps * op.Cin_p + op.Cin2_p) / 16;
+  if (op.osplit && op.osplit % 16) return false;
+  static const bool allow_direct = !(getenv("TREBI_CHAIN_DIRECT") && atoi(getenv("TREBI_CHAIN_DIRECT")) == 0);
+  auto pro_ok = [&](int nteams16) {
+    if (!op.pro) return true;
+    if (op.stride != 1 || op.Lin != op.Lout || op.pro_gn.gch % 4 || op.Cin % 16) return false;
+    const int ts = (S * GN_GROUPS * 4 <= nteams16) ? 64 : 16;
+    return op.Lin * (op.pro_gn.gch / 4) <= 2 * ts && S * GN_GROUPS <= 16 * nteams16 / ts;
+  };
+  if (allow_direct && (op.Lout == 16 || op.Lout == 32)) {
+    const int MS = S * op.Lout / 16;
+    bool ok = MS * NG <= 8;
+    if (op.gn) {
+      const int gch = op.gnw.gch;
+      ok = ok && op.Npad == op.N && op.N % GN_GROUPS == 0 &&
+           ((NI == 1 && (gch == 4 || gch == 8 || gch == 16)) || (NI == 2 && gch == 32));
+    }
+    if (ok && pro_ok(4 * NG * MS)) {
+      *out = Tile{MS, NI, NG, MS, S};                 // MI = KS = row tiles: TM = 16*MS, 64*NG*MS threads
+      *direct = true;
+      return true;
+    }
+  }
+  *direct = false;
   const int MI = pow2ceil((S * op.Lout + 15) / 16);
   if (!chain_variant_ok(MI, NI)) return false;
-  const int KK = (op.ntaps * op.Cin_p + op.Cin2_p) / 16;
   const int KS = std::max(1, std::min(8 / NG, std::max(1, KK / 4)));
   const int nteams16 = 4 * NG * KS;
   if (op.gn) {
@@ -1048,12 +1073,7 @@ bool chain_tile(const Op& op, int S, int max_n, Tile* out) {
     const int ts = (S * GN_GROUPS * 4 <= nteams16) ? 64 : 16;       // all groups sit in the one column tile
     if (op.Lout * (op.gnw.gch / 4) > 2 * ts) return false;          // a team keeps its group in registers
   }
-  if (op.pro) {
-    if (op.stride != 1 || op.Lin != op.Lout || op.pro_gn.gch % 4 || op.Cin % 16) return false;
-    const int ts = (S * GN_GROUPS * 4 <= nteams16) ? 64 : 16;
-    if (op.Lin * (op.pro_gn.gch / 4) > 2 * ts || S * GN_GROUPS > 64 * NG * KS / ts) return false;
-  }
-  if (op.osplit && op.osplit % 16) return false;
+  if (!pro_ok(nteams16)) return false;
   *out = Tile{MI, NI, NG, KS, S};
   return true;
 }
@@ -1063,12 +1083,15 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
                   const Resolver* r1, int B, int S, int max_n, std::vector<RStage>& tab, Plan& plan) {
   const int nz = r1 ? 2 : 1;
   std::vector<Tile> tiles;
+  std::vector<char> directs;
   size_t j = i;
   static const size_t max_len = getenv("TREBI_CHAIN_MAXLEN") ? (size_t)atoi(getenv("TREBI_CHAIN_MAXLEN")) : 1000;
   while (j < o0.size() && j - i < max_len) {
     Tile tl;
-    if (!chain_tile(*o0[j], S, max_n, &tl)) break;
+    bool direct = false;
+    if (!chain_tile(*o0[j], S, max_n, &tl, &direct)) break;
     tiles.push_back(tl);
+    directs.push_back(direct);
     ++j;
   }
   struct Key {
@@ -1103,6 +1126,7 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
       if (r1) st.p[1] = r1->conv(*o1[i + k]);
       const Tile& tl = tiles[k];
       st.MI = tl.MI; st.NI = tl.NI;
+      st.direct = directs[k];
       st.vec = conv_vec_ok(st.p[0]) && (!r1 || conv_vec_ok(st.p[1]));
       st.g = conv_make_geo(st.p[0], tl);
       const ConvGeo& G = st.g;
@@ -1184,10 +1208,14 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
       if (!st.srcRes) slabsz = std::max(slabsz, (size_t)S * G.R * G.ldA);
       if (op.Cin2_p && !have_2) slab2sz = std::max(slab2sz, (size_t)S * op.Lout * G.ld2);
       if (op.res.id != NONE && !have_r) restsz = std::max(restsz, (size_t)G.TM * G.TNp);
-      redsz = std::max(redsz, (size_t)G.red1);
-      if (op.Cin2_p) red2sz = std::max(red2sz, (size_t)G.red1);
-      colsz = std::max(colsz, (size_t)4 * G.TN);
-      if (op.tbias) tbsz = std::max(tbsz, (size_t)S * G.TN);
+      if (st.direct) {
+        redsz = std::max(redsz, (size_t)8 * 2 * 16 * 2);       // (mean, M2) exchange between row-tile waves
+      } else {
+        redsz = std::max(redsz, (size_t)G.red1);
+        if (op.Cin2_p) red2sz = std::max(red2sz, (size_t)G.red1);
+        colsz = std::max(colsz, (size_t)4 * G.TN);
+        if (op.tbias) tbsz = std::max(tbsz, (size_t)S * G.TN);
+      }
       fl += op.flops * B * nz;
     }
     if (run.empty()) continue;
