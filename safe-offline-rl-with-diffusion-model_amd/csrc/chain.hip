@@ -64,34 +64,108 @@ __device__ __forceinline__ void wload(f32x4 (&w)[WREG], const float* pw, unsigne
   }
 }
 
-// First weight block of a stage, for the wave `wave` (any stage: used for stage 0 and as the prefetch).
-// Direct stages keep a block of n < WH steps in the LAST n register slots (see the K loop).
-__device__ __forceinline__ void wfirst(const RStage& st, int z, int wave, int lane, f32x4 (&w)[WREG]) {
-  const int NG = st.g.NG, KS = st.g.KS, NI = st.NI;
-  if (wave >= NG * KS) return;
-  const int ks = FastDiv(NG, st.g.mNG).div(wave), ng = wave - ks * NG;
-  const int Npad = st.p[z].Npad;
-  const unsigned wlane = (unsigned)(((lane >> 4) * Npad + ng * NI * 16 + (lane & 15)) * 4);
-  const unsigned wstep = (unsigned)Npad * 16u;
-  if (st.direct) {
-    const int WH = WREG / NI;
-    const int lim = st.g.KK1 > 0 ? st.g.KK1 : st.g.KK;
-    const int n = lim < WH ? lim : WH;
-    const float* wu = st.p[z].w + wlane;
-    if (NI == 1) {
+// What a wave needs to know about a stage to request its first weights.
+struct WInfo {
+  const float* w;
+  int Npad, NG, KS, NI, chunk, KK, KK1, direct;
+  unsigned mNG;
+};
+// ---- stage descriptors live in VGPRs ---------------------------------------------------------------
+// Reading descriptor fields with scalar loads costs a scalar-cache round trip (hundreds of cycles) at
+// every point the compiler decides to (re)load one -- dozens of serialized waits per stage.  Instead each
+// wave keeps the stage's descriptor view (its net's ConvP followed by the shared part of RStage) spread
+// over the lanes of 4 VGPRs, loaded with ordinary vector loads one stage ahead; a field is then one
+// v_readlane_b32 with a constant lane: no memory access, no wait.
+constexpr int PW = (int)(sizeof(ConvP) / 4);
+constexpr int TAIL0 = (int)offsetof(RStage, g);
+constexpr int VIEW_DW = PW + (int)((sizeof(RStage) - TAIL0) / 4);
+static_assert(VIEW_DW <= 256, "descriptor view must fit 4 VGPRs");
+static_assert(sizeof(ConvP) % 4 == 0 && TAIL0 % 4 == 0 && sizeof(RStage) % 4 == 0, "dword layout");
+struct DV { unsigned v[4]; };
+__device__ __forceinline__ void dload(DV& d, const RStage* st, int z, int lane) {
+  const unsigned* base = (const unsigned*)st;
 #pragma unroll
-      for (int u = 0; u < WREG; ++u)
-        if (u >= WREG - n) { w[u] = gld4(wu); wu += wstep; }
+  for (int k = 0; k < 4; ++k) {
+    const int j = lane + 64 * k;
+    const int src = j < PW ? z * PW + j : TAIL0 / 4 + (j - PW);
+    d.v[k] = j < VIEW_DW ? *(const TREBI_GLOBAL unsigned*)(base + src) : 0u;
+  }
+}
+template <int IDX>
+__device__ __forceinline__ unsigned dget(const DV& d) {
+  return (unsigned)__builtin_amdgcn_readlane((int)d.v[IDX >> 6], IDX & 63);
+}
+template <typename T, int IDX>
+__device__ __forceinline__ T dfield(const DV& d) {
+  if constexpr (sizeof(T) == 4) {
+    union { unsigned u; T t; } c;
+    c.u = dget<IDX>(d);
+    return c.t;
+  } else {
+    static_assert(sizeof(T) == 8, "descriptor fields are 4 or 8 bytes");
+    union { unsigned long long u; T t; } c;
+    c.u = (unsigned long long)dget<IDX>(d) | ((unsigned long long)dget<IDX + 1>(d) << 32);
+    return c.t;
+  }
+}
+#define DPF(d, f) dfield<decltype(ConvP::f), (int)(offsetof(ConvP, f) / 4)>(d)
+#define DGF(d, f) dfield<decltype(ConvGeo::f), PW + (int)((offsetof(RStage, g) + offsetof(ConvGeo, f) - TAIL0) / 4)>(d)
+#define DSF(d, f) dfield<decltype(RStage::f), PW + (int)((offsetof(RStage, f) - TAIL0) / 4)>(d)
+#define DP(f) DPF(dv, f)
+#define DG(f) DGF(dv, f)
+#define DS(f) DSF(dv, f)
+
+__device__ __forceinline__ WInfo winfo_of(const DV& d) {
+  return WInfo{DPF(d, w), DPF(d, Npad), DGF(d, NG), DGF(d, KS), DSF(d, NI), DGF(d, chunk), DGF(d, KK), DGF(d, KK1),
+               DSF(d, direct), DGF(d, mNG)};
+}
+
+// Direct stages walk the reduction in blocks of up to WH = WREG/NI steps that never straddle the two
+// sources (steps [0, KK1) read the primary source, [KK1, KK) the 1x1 source); block i covers [kb, kb + n).
+struct Blk { int kb, n; };
+__device__ __forceinline__ Blk blk_of(int i, int sh, int KK1, int KK) {
+  const int WH = 1 << sh, nb1 = (KK1 + WH - 1) >> sh;
+  const int kb = i < nb1 ? (i << sh) : KK1 + ((i - nb1) << sh);
+  const int ke = i < nb1 ? KK1 : KK;
+  int n = ke - kb;
+  n = n < 0 ? 0 : (n > WH ? WH : n);
+  return Blk{kb, n};
+}
+// weights of a block into the LAST n slots of w (the K loop enters its unrolled step sequence at slot WH-n)
+template <int NI>
+__device__ __forceinline__ void wblk(f32x4 (&w)[WREG], const float* pw, unsigned wstep, unsigned wlane, Blk b) {
+  constexpr int WH = WREG / NI;
+  const float* wu = pw + (size_t)b.kb * wstep + wlane;
+#pragma unroll
+  for (int u = 0; u < WH; ++u) {
+    if (u >= WH - b.n) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) w[u * NI + ni] = gld4(wu + ni * 64);
+      wu += wstep;
+    }
+  }
+}
+
+// Request the first weights of a stage: direct stages the first three blocks (a whole narrow layer), split-K
+// stages the first block of the wave's K range.  Issued a stage ahead, before the epilogue.
+__device__ __forceinline__ void wprefetch(const WInfo& q, int wave, int lane, f32x4 (&w)[3][WREG]) {
+  if (wave >= q.NG * q.KS) return;
+  const int ks = FastDiv(q.NG, q.mNG).div(wave), ng = wave - ks * q.NG;
+  const unsigned wlane = (unsigned)(((lane >> 4) * q.Npad + ng * q.NI * 16 + (lane & 15)) * 4);
+  const unsigned wstep = (unsigned)q.Npad * 16u;
+  if (q.direct) {
+    if (q.NI == 1) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) wblk<1>(w[i], q.w, wstep, wlane, blk_of(i, 3, q.KK1, q.KK));
     } else {
 #pragma unroll
-      for (int u = 0; u < WREG / 2; ++u)
-        if (u >= WREG / 2 - n) { w[2 * u] = gld4(wu); w[2 * u + 1] = gld4(wu + 64); wu += wstep; }
+      for (int i = 0; i < 3; ++i) wblk<2>(w[i], q.w, wstep, wlane, blk_of(i, 2, q.KK1, q.KK));
     }
     return;
   }
-  const int kb = ks * st.g.chunk;
-  const int ke = kb + st.g.chunk < st.g.KK ? kb + st.g.chunk : st.g.KK;
-  wload(w, st.p[z].w, wstep, wlane, NI, kb, ke);
+  const int kb = ks * q.chunk;
+  const int ke = kb + q.chunk < q.KK ? kb + q.chunk : q.KK;
+  wload(w[0], q.w, wstep, wlane, q.NI, kb, ke);
 }
 
 // Sum over aligned groups of `lanes` (4, 8 or 16) lanes of each 16-lane row; VALU only.
@@ -108,43 +182,41 @@ __device__ __forceinline__ f32x4 ld4(const float* sp, int left, bool vec) {
 }
 
 template <int MI, int NI, bool DIRECT>
-__device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, const int z, float* smem, const int tid,
+__device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool has_next, float* smem, const int tid,
                                          const int b0, int t_uniform, const long long* tptr,
-                                         f32x4 (&wreg)[2][WREG], int skey, int sidx) {
+                                         f32x4 (&wreg)[3][WREG], int skey, int sidx) {
   constexpr int WH = WREG / NI;    // reduction steps per register half
   CSTAMP(0);
-  const ConvP& p = st.p[z];
-  const ConvGeo& G = st.g;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  const float* px = p.x;  const float* pw = p.w;  float* pout = p.out;
-  int ldx = p.ldx, Cin = p.Cin, Lin = p.Lin, Lout = p.Lout, stride = p.stride, B = p.B, N = p.N, Npad = p.Npad;
-  int S = G.S, NG = G.NG, KS = G.KS, nthr = G.nthr, TM = G.TM, TN = G.TN, TNp = G.TNp, R = G.R, ldA = G.ldA,
-      ld2 = G.ld2;
-  int cbpt = G.cbpt, KK1 = G.KK1, KK = G.KK, chunk = G.chunk, nv = G.nv, fh = G.fh;
-  int Rb = st.Rb, a0 = st.a0, Rb2 = st.Rb2, h2 = st.h2;
+  const float* px = DP(x);  const float* pw = DP(w);  float* pout = DP(out);
+  int ldx = DP(ldx), Cin = DP(Cin), Lin = DP(Lin), Lout = DP(Lout), stride = DP(stride), B = DP(B), N = DP(N), Npad = DP(Npad);
+  int S = DG(S), NG = DG(NG), KS = DG(KS), nthr = DG(nthr), TM = DG(TM), TN = DG(TN), TNp = DG(TNp), R = DG(R), ldA = DG(ldA),
+      ld2 = DG(ld2);
+  int cbpt = DG(cbpt), KK1 = DG(KK1), KK = DG(KK), chunk = DG(chunk), nv = DG(nv), fh = DG(fh);
+  int Rb = DS(Rb), a0 = DS(a0), Rb2 = DS(Rb2), h2 = DS(h2);
   PIN(px); PIN(pw); PIN(pout); PIN(ldx); PIN(Cin); PIN(Lin); PIN(Lout); PIN(stride); PIN(B); PIN(N); PIN(Npad);
   PIN(S); PIN(NG); PIN(KS); PIN(nthr); PIN(TM); PIN(TN); PIN(TNp); PIN(R); PIN(ldA); PIN(ld2);
   PIN(cbpt); PIN(KK1); PIN(KK); PIN(chunk); PIN(nv); PIN(fh); PIN(Rb); PIN(a0); PIN(Rb2); PIN(h2);
   CSTAMP(7);
-  const bool has2 = p.Cin2_p != 0, haspro = p.pro != 0, hasres = p.res != nullptr || st.resRes,
-             hastb = p.tbias != nullptr, hasgn = p.gn != 0;
-  const bool vec = st.vec != 0;
+  const bool has2 = DP(Cin2_p) != 0, haspro = DP(pro) != 0, hasres = DP(res) != nullptr || DS(resRes),
+             hastb = DP(tbias) != nullptr, hasgn = DP(gn) != 0;
+  const bool vec = DS(vec) != 0;
   const bool active = tid < nthr;
-  float* slab = smem + st.oSrc;
-  float* slab2 = smem + st.o2;
-  float* resb = smem + st.oR;
-  float* dreg = smem + st.oD;
-  float* red = smem + st.oRed;
-  float* red2 = smem + st.oRed2;
-  float* colp = smem + st.oColp;         // [4][TN]: bias, gamma, beta, bias2
-  float* tbrow = smem + st.oTb;          // [S][TN]
-  const FastDiv dLout(Lout, G.mLout), dTN4(G.tn4, G.mTN4), dTN(TN, G.mTN);
+  float* slab = smem + DS(oSrc);
+  float* slab2 = smem + DS(o2);
+  float* resb = smem + DS(oR);
+  float* dreg = smem + DS(oD);
+  float* red = smem + DS(oRed);
+  float* red2 = smem + DS(oRed2);
+  float* colp = smem + DS(oColp);         // [4][TN]: bias, gamma, beta, bias2
+  float* tbrow = smem + DS(oTb);          // [S][TN]
+  const FastDiv dLout(Lout, DG(mLout)), dTN4(DG(tn4), DG(mTN4)), dTN(TN, DG(mTN));
   const int nvs = (B - b0 < S) ? B - b0 : S;       // candidates of this tile that exist
 
   const int g = lane >> 4, lr = lane & 15;
-  const int ks = FastDiv(NG, G.mNG).div(wave), ng = wave - ks * NG;
+  const int ks = FastDiv(NG, DG(mNG)).div(wave), ng = wave - ks * NG;
   // split-K stages: wave = (K split ks, column group ng); direct stages: wave = (row tile ks, column group ng)
   const int k_begin = (active && !DIRECT) ? ks * chunk : 0;
   const int k_end = active ? (DIRECT ? KK : ((k_begin + chunk < KK) ? k_begin + chunk : KK)) : 0;
@@ -154,7 +226,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
 
   // ---- phase A: everything this stage reads from global memory --------------------------------
   // GroupNorm-backward operands of this thread's team (registers): saved mish'(z)*gamma and xhat
-  const int ts_pro = G.ts_pro;
+  const int ts_pro = DG(ts_pro);
   const int pteam = ts_pro == 64 ? (tid >> 6) : (tid >> 4), ptl = tid & (ts_pro - 1);
   f32x4 pg_[2], px_[2];
   int po_[2] = {-1, -1}, pi_[2] = {0, 0};
@@ -165,19 +237,19 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
     const int s = inst >> 3, gi = inst & 7;
     if (inst < S * GN_GROUPS && s < nvs) {
       pinst = true;
-      const int gch = p.pro_gch, pg4 = G.pgch4, cnt4 = G.pcnt4;
-      const FastDiv dG(pg4, G.mPGch4);
-      prstd = gld(p.pro_stats + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2 + 1);
+      const int gch = DP(pro_gch), pg4 = DG(pgch4), cnt4 = DG(pcnt4);
+      const FastDiv dG(pg4, DG(mPGch4));
+      prstd = gld(DP(pro_stats) + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2 + 1);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int e = ptl + j * ts_pro;
         if (e < cnt4) {
           const int li = dG.div(e), c = gi * gch + 4 * (e - li * pg4);
-          po_[j] = (s * Rb + st.pr0 + li) * ldA + c;
-          pi_[j] = st.proRes ? (s * (Lin + 4) + 2 + li) * ldA + c : po_[j];
+          po_[j] = (s * Rb + DS(pr0) + li) * ldA + c;
+          pi_[j] = DS(proRes) ? (s * (Lin + 4) + 2 + li) * ldA + c : po_[j];
           const unsigned go = ((unsigned)(b0 + s) * Lin + li) * (unsigned)Cin + c;
-          pg_[j] = gld4(p.pro_g + go);
-          px_[j] = gld4(p.pro_y + go);
+          pg_[j] = gld4(DP(pro_g) + go);
+          px_[j] = gld4(DP(pro_y) + go);
         }
       }
     }
@@ -195,33 +267,33 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
     int s = dTN.div(e), c = e - s * TN;
     if (s >= nvs || c >= N) return 0.f;
     long long tt = t_uniform >= 0 ? t_uniform : gldll(tptr + b0 + s);
-    tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
-    return gld(p.tbias + (unsigned)tt * (unsigned)N + c);
+    tt = tt < 0 ? 0 : (tt >= DP(T) ? DP(T) - 1 : tt);
+    return gld(DP(tbias) + (unsigned)tt * (unsigned)N + c);
   };
   if (active) {
     if (DIRECT) {
       long long tt = 0;
       if (hastb) {
         tt = t_uniform >= 0 ? t_uniform : (sw < nvs ? gldll(tptr + b0 + sw) : 0);
-        tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
+        tt = tt < 0 ? 0 : (tt >= DP(T) ? DP(T) - 1 : tt);
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int n = (ng * NI + ni) * 16 + lr;
         const bool ok = n < N;
-        dbias[ni] = (ok && p.bias) ? gld(p.bias + n) : 0.f;
-        dgam[ni] = (ok && hasgn) ? gld(p.gamma + n) : 1.f;
-        dbet[ni] = (ok && hasgn) ? gld(p.beta + n) : 0.f;
-        dbi2[ni] = (ok && p.bias2) ? gld(p.bias2 + n) : 0.f;
-        dtb[ni] = (ok && hastb) ? gld(p.tbias + (unsigned)tt * (unsigned)N + n) : 0.f;
+        dbias[ni] = (ok && DP(bias)) ? gld(DP(bias) + n) : 0.f;
+        dgam[ni] = (ok && hasgn) ? gld(DP(gamma) + n) : 1.f;
+        dbet[ni] = (ok && hasgn) ? gld(DP(beta) + n) : 0.f;
+        dbi2[ni] = (ok && DP(bias2)) ? gld(DP(bias2) + n) : 0.f;
+        dtb[ni] = (ok && hastb) ? gld(DP(tbias) + (unsigned)tt * (unsigned)N + n) : 0.f;
       }
     }
     if (colt) {
       const int n = tid;
       const bool ok = n < N;
-      if (ok && p.bias) c0 = gld(p.bias + n);
-      if (ok && hasgn) { c1 = gld(p.gamma + n); c2 = gld(p.beta + n); }
-      if (ok && p.bias2) c3 = gld(p.bias2 + n);
+      if (ok && DP(bias)) c0 = gld(DP(bias) + n);
+      if (ok && hasgn) { c1 = gld(DP(gamma) + n); c2 = gld(DP(beta) + n); }
+      if (ok && DP(bias2)) c3 = gld(DP(bias2) + n);
     }
     if (hastb && !DIRECT) {
 #pragma unroll
@@ -229,21 +301,21 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
         if (tid + u * nthr < S * TN) tbv[u] = tb_load(tid + u * nthr);
     }
     // identity residual from global memory -> tile [TM][TNp]
-    if (hasres && !st.resRes) {
-      const int nRes4 = G.nRes4;
+    if (hasres && !DS(resRes)) {
+      const int nRes4 = DG(nRes4);
       for (int e = tid; e < nRes4; e += nthr) {
-        int row = dTN4.div(e), c4 = e - row * G.tn4;
+        int row = dTN4.div(e), c4 = e - row * DG(tn4);
         int left = N - 4 * c4;
         if (row >= nvs * Lout) left = 0;
-        const float* sp = p.res + ((unsigned)b0 * Lout + row) * (unsigned)p.ldres + 4 * c4;
-        *(f32x4*)&resb[row * TNp + 4 * c4] = G.vecr ? load4<true>(sp, left) : load4<false>(sp, left);
+        const float* sp = DP(res) + ((unsigned)b0 * Lout + row) * (unsigned)DP(ldres) + 4 * c4;
+        *(f32x4*)&resb[row * TNp + 4 * c4] = DG(vecr) ? load4<true>(sp, left) : load4<false>(sp, left);
       }
     }
     // primary source from global memory -> slab [S][R][ldA] with a zero halo (with a resident gradient
     // only the halo: the prologue writes the rows)
-    if (!st.srcRes) {
-      const FastDiv dC4(G.c4n, G.mC4), dNv(nv, G.mNv);
-      const int c4n = G.c4n, total = st.proRes ? 0 : G.nValid4, vlo = G.vlo;
+    if (!DS(srcRes)) {
+      const FastDiv dC4(DG(c4n), DG(mC4)), dNv(nv, DG(mNv));
+      const int c4n = DG(c4n), total = DS(proRes) ? 0 : DG(nValid4), vlo = DG(vlo);
       for (int base = tid; base < total; base += 4 * nthr) {
         f32x4 v[4];
         int so[4];
@@ -264,8 +336,8 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
         for (int u = 0; u < 4; ++u)
           if (so[u] >= 0) *(f32x4*)&slab[so[u]] = v[u];
       }
-      const FastDiv dHr(G.hr, G.mHr);
-      const int nh = G.nHalo4, hr = G.hr;
+      const FastDiv dHr(DG(hr), DG(mHr));
+      const int nh = DG(nHalo4), hr = DG(hr);
       for (int idx = tid; idx < nh; idx += nthr) {
         int h = dC4.div(idx), c4 = idx - h * c4n;
         int s = dHr.div(h), k = h - s * hr;
@@ -273,11 +345,11 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
         *(f32x4*)&slab[(s * R + j) * ldA + 4 * c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
-    if (has2 && !st.x2Res) {            // second source rows at the output positions -> slab2 [S*Lout][ld2]
-      const FastDiv dC4(G.c4n2, G.mC4b);
-      const int c4n = G.c4n2, total = G.nX24, C2 = p.Cin2;
-      const float* p2 = p.x2;
-      const unsigned ldx2 = p.ldx2;
+    if (has2 && !DS(x2Res)) {            // second source rows at the output positions -> slab2 [S*Lout][ld2]
+      const FastDiv dC4(DG(c4n2), DG(mC4b));
+      const int c4n = DG(c4n2), total = DG(nX24), C2 = DP(Cin2);
+      const float* p2 = DP(x2);
+      const unsigned ldx2 = DP(ldx2);
       for (int base = tid; base < total; base += 2 * nthr) {
         f32x4 v[2];
         int so[2] = {-1, -1};
@@ -297,26 +369,26 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
       }
     }
     // zero halo rows of the resident destination (2 in front, 2 behind every candidate)
-    if (st.dstRes) {
-      const int ld4n = st.ldD >> 2, tot = S * 4 * ld4n;
-      const FastDiv dL4(ld4n, st.mLd4);
+    if (DS(dstRes)) {
+      const int ld4n = DS(ldD) >> 2, tot = S * 4 * ld4n;
+      const FastDiv dL4(ld4n, DS(mLd4));
       for (int idx = tid; idx < tot; idx += nthr) {
         int h = dL4.div(idx), c4 = idx - h * ld4n;
         int s = h >> 2, k = h & 3;
-        int row = s * st.RbD + (k < 2 ? k : st.Ld + k);
-        *(f32x4*)&dreg[row * st.ldD + 4 * c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int row = s * DS(RbD) + (k < 2 ? k : DS(Ld) + k);
+        *(f32x4*)&dreg[row * DS(ldD) + 4 * c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
   }
   CSTAMP(1);
-  if ((!st.srcRes && !st.proRes) || (has2 && !st.x2Res)) lds_barrier();     // staged operands visible to every wave
+  if ((!DS(srcRes) && !DS(proRes)) || (has2 && !DS(x2Res))) lds_barrier();     // staged operands visible to every wave
 
   // ---- prologue: GroupNorm backward of the producing Conv1dBlock ----------------------------------
   //   d = dA * mish'(z)*gamma;  dY = rstd * (d - mean_g(d) - xhat * mean_g(d * xhat))
   // dA is read from the staged slab or from the resident gradient (left untouched: the residual path of the
   // next layer reads it again); dY always lands in the slab the K loop reads.
   if (haspro) {
-    const float* pin = smem + (st.proRes ? st.oPro : st.oSrc);
+    const float* pin = smem + (DS(proRes) ? DS(oPro) : DS(oSrc));
     if (active && pteam < S * GN_GROUPS) {
       f32x4 d[2];
       float s1 = 0.f, s2 = 0.f;
@@ -329,7 +401,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
           s2 += hsum(d[j] * px_[j]);
         }
       }
-      const float icnt = 1.f / (float)(G.pcnt4 * 4);
+      const float icnt = 1.f / (float)(DG(pcnt4) * 4);
       const float m1 = team_sum(s1, ts_pro) * icnt, m2 = team_sum(s2, ts_pro) * icnt;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -356,32 +428,14 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
     // hides the LDS latency -- and the weights of the next block travel meanwhile.
     const int r = rowbase + lr;
     const int s = dLout.div(r), lo = r - s * Lout;
-    const int offA = st.oSrc + (s * Rb + lo * stride + a0) * ldA + 4 * g;
-    const int off2 = st.o2 + (s * Rb2 + h2 + lo) * ld2 + 4 * g;
-    const int KK2 = KK - KK1;
-    const int nb1 = (KK1 + WH - 1) / WH, nb = nb1 + (KK2 + WH - 1) / WH;
-    const FastDiv dCb(cbpt, G.mCbpt);
-    // block i: [kb, kb+n) of source 1 (i < nb1) or of source 2
-    auto blk_kb = [&](int i) { return i < nb1 ? i * WH : KK1 + (i - nb1) * WH; };
-    auto blk_n = [&](int i) {
-      const int kb = blk_kb(i), ke = i < nb1 ? KK1 : KK;
-      return ke - kb < WH ? ke - kb : WH;
-    };
-    // weights of block i into the last n slots of w
-    auto wblk = [&](f32x4 (&w)[WREG], int i) {
-      const int kb = blk_kb(i), n = blk_n(i);
-      const float* wu = pw + (size_t)kb * wstep + wlane;
-#pragma unroll
-      for (int u = 0; u < WH; ++u) {
-        if (u >= WH - n) {
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) w[u * NI + ni] = gld4(wu + ni * 64);
-          wu += wstep;
-        }
-      }
-    };
+    const int offA = DS(oSrc) + (s * Rb + lo * stride + a0) * ldA + 4 * g;
+    const int off2 = DS(o2) + (s * Rb2 + h2 + lo) * ld2 + 4 * g;
+    constexpr int SH = NI == 1 ? 3 : 2;
+    const int nb1 = (KK1 + WH - 1) >> SH, nb = nb1 + ((KK - KK1 + WH - 1) >> SH);
+    const FastDiv dCb(cbpt, DG(mCbpt));
     auto run = [&](const f32x4 (&w)[WREG], int i) {
-      const int kb = blk_kb(i), n = blk_n(i);
+      const Blk bk = blk_of(i, SH, KK1, KK);
+      const int kb = bk.kb, n = bk.n;
       f32x4 a[WH];
       if (i < nb1) {
         int tau = dCb.div(kb);
@@ -432,12 +486,17 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
 #undef TREBI_STEP
       }
     };
-    for (int i = 0; i < nb; i += 2) {
-      if (i + 1 < nb) wblk(wreg[1], i + 1);
+    // blocks 0..2 were requested a stage ahead; a slot is refilled as soon as its block is done
+    for (int i = 0; i < nb; i += 3) {
       run(wreg[0], i);
+      if (i + 3 < nb) wblk<NI>(wreg[0], pw, wstep, wlane, blk_of(i + 3, SH, KK1, KK));
       if (i + 1 < nb) {
-        if (i + 2 < nb) wblk(wreg[0], i + 2);
         run(wreg[1], i + 1);
+        if (i + 4 < nb) wblk<NI>(wreg[1], pw, wstep, wlane, blk_of(i + 4, SH, KK1, KK));
+      }
+      if (i + 2 < nb) {
+        run(wreg[2], i + 2);
+        if (i + 5 < nb) wblk<NI>(wreg[2], pw, wstep, wlane, blk_of(i + 5, SH, KK1, KK));
       }
     }
   }
@@ -451,7 +510,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
       rowA[mi] = ok ? (s * Rb + lo * stride + a0) * ldA + 4 * g : 4 * g;
       row2[mi] = ok ? (s * Rb2 + h2 + lo) * ld2 + 4 * g : 4 * g;
     }
-    const FastDiv dCb(cbpt, G.mCbpt);
+    const FastDiv dCb(cbpt, DG(mCbpt));
     int cb, aoff;
     {
       int tau = dCb.div(k_begin);
@@ -518,7 +577,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
   }
   CSTAMP(3);
   // the next stage's first weight block travels while this stage reduces and normalises
-  if (nx) wfirst(*nx, z, wave, lane, wreg[0]);
+  if (has_next) wprefetch(winfo_of(dvn), wave, lane, wreg);
 
   const int kstride = TM * TNp;
   if (!DIRECT) {
@@ -543,11 +602,11 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
     // MFMA C layout: lane holds column lr of each sub-tile, rows 4*g + q.  The 16 rows belong to ONE
     // candidate (Lout is 16 or 32, checked on the host); with Lout == 32 the other half of the candidate is
     // the wave with the neighbouring row tile, and the two exchange (mean, M2) through LDS once.
-    const FastDiv dOs(p.osplit > 0 ? p.osplit : 1, G.mOs);
-    const int osplit = p.osplit;
-    const unsigned ldo = p.ldo;
-    const int RbR = st.RbR, hR = st.hR, ldR = st.ldR, RbD = st.RbD, ldD = st.ldD;
-    const bool dstRes = st.dstRes != 0;
+    const FastDiv dOs(DP(osplit) > 0 ? DP(osplit) : 1, DG(mOs));
+    const int osplit = DP(osplit);
+    const unsigned ldo = DP(ldo);
+    const int RbR = DS(RbR), hR = DS(hR), ldR = DS(ldR), RbD = DS(RbD), ldD = DS(ldD);
+    const bool dstRes = DS(dstRes) != 0;
     const int lo0 = rowbase - sw * Lout + 4 * g;
     const bool live = active && sw < nvs;
     const bool two = Lout > 16;
@@ -562,7 +621,7 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
       for (int q = 0; q < 4; ++q) v[ni][q] = acc[0][ni][q] + dbias[ni];
     }
     float* xch = red;                                  // [wave][NI][16][2]
-    const int gch = p.gch;
+    const int gch = DP(gch);
     if (hasgn && active) {
       const int rl = gch < 16 ? gch : 16;              // lanes of a 16-lane row that share a group
       const bool both = NI == 2 && gch > 16;           // the group spans both sub-tiles of the wave
@@ -604,9 +663,9 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
     }
     if (hasgn && two) lds_barrier();
     if (live) {
-      const FastDiv dG(G.gch4, G.mGch4);
-      float* sy = p.save_y;
-      float* sg = p.save_g;
+      const FastDiv dG(DG(gch4), DG(mGch4));
+      float* sy = DP(save_y);
+      float* sg = DP(save_g);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int col = cols[ni];
@@ -629,8 +688,8 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
           }
           rstd = __frsqrt_rn(M2 / cnt + GN_EPS);
           const int gi = dG.div(col >> 2);
-          if (p.save_stats && g == 0 && (col & (gch - 1)) == 0 && (!two || (ks & 1) == 0)) {
-            float* o = p.save_stats + ((unsigned)(b0 + sw) * GN_GROUPS + gi) * 2;
+          if (DP(save_stats) && g == 0 && (col & (gch - 1)) == 0 && (!two || (ks & 1) == 0)) {
+            float* o = DP(save_stats) + ((unsigned)(b0 + sw) * GN_GROUPS + gi) * 2;
             gst(o, mean);
             gst(o + 1, rstd);
           }
@@ -668,12 +727,12 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
   }
   if (!active) return;
 
-  const FastDiv dOs(p.osplit > 0 ? p.osplit : 1, G.mOs);
-  const int osplit = p.osplit;
-  const unsigned ldo = p.ldo;
-  const bool veco = G.veco != 0;
-  const int RbR = st.RbR, hR = st.hR, ldR = st.ldR, RbD = st.RbD, ldD = st.ldD;
-  const bool dstRes = st.dstRes != 0;
+  const FastDiv dOs(DP(osplit) > 0 ? DP(osplit) : 1, DG(mOs));
+  const int osplit = DP(osplit);
+  const unsigned ldo = DP(ldo);
+  const bool veco = DG(veco) != 0;
+  const int RbR = DS(RbR), hR = DS(hR), ldR = DS(ldR), RbD = DS(RbD), ldD = DS(ldD);
+  const bool dstRes = DS(dstRes) != 0;
   // finish 4 adjacent output columns of (candidate s, position lo): time bias, second-source sum,
   // residual, then the resident copy and / or the global store
   auto finish = [&](f32x4 v, int s, int lo, int col) {
@@ -708,14 +767,14 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
   if (hasgn) {
     // split-K reduce + bias, GroupNorm statistics, normalise, Mish: a team per (candidate, group), the
     // team's values (at most 2 float4 per lane, checked on the host) stay in registers between passes
-    const int gch = p.gch, g4 = G.gch4, cnt4 = G.cnt4, gpt = G.gpt, ninst = S * gpt;
-    const int ts = G.ts_epi;
+    const int gch = DP(gch), g4 = DG(gch4), cnt4 = DG(cnt4), gpt = DG(gpt), ninst = S * gpt;
+    const int ts = DG(ts_epi);
     const int team = ts == 64 ? (tid >> 6) : (tid >> 4), tl = tid & (ts - 1),
               nteams = ts == 64 ? (nthr >> 6) : (nthr >> 4);
-    const FastDiv dG(g4, G.mGch4), dGpt(gpt, G.mGpt);
+    const FastDiv dG(g4, DG(mGch4)), dGpt(gpt, DG(mGpt));
     const float icnt = 1.f / (float)(cnt4 * 4);
-    float* sy = p.save_y;
-    float* sg = p.save_g;
+    float* sy = DP(save_y);
+    float* sg = DP(save_g);
     for (int inst = team; inst < ninst; inst += nteams) {
       int s = dGpt.div(inst), gi = inst - s * gpt;
       if (s >= nvs) continue;
@@ -750,8 +809,8 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
         }
       const float rstd = 1.f / sqrtf(team_sum(sq, ts) * icnt + GN_EPS);
       CSTAMP(11);
-      if (tl == 0 && p.save_stats) {
-        float* o = p.save_stats + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2;
+      if (tl == 0 && DP(save_stats)) {
+        float* o = DP(save_stats) + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2;
         gst(o, mean);
         gst(o + 1, rstd);
       }
@@ -780,9 +839,9 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
         }
     }
   } else {
-    const int nitems = G.nRes4;            // TM * TN / 4
+    const int nitems = DG(nRes4);            // TM * TN / 4
     for (int e = tid; e < nitems; e += nthr) {
-      int row = dTN4.div(e), col = 4 * (e - row * G.tn4);
+      int row = dTN4.div(e), col = 4 * (e - row * DG(tn4));
       if (row >= nvs * Lout || col >= N) continue;
       int s = dLout.div(row);
       f32x4 v = *(const f32x4*)&colp[col];
@@ -795,34 +854,39 @@ __device__ __forceinline__ void rc_stage(const RStage& st, const RStage* nx, con
 
 }  // namespace
 
+// DIRECT: every stage is a direct stage (one kernel per stage kind keeps each kernel's register
+// footprint within two waves per SIMD without spilling).
+template <bool DIRECT>
 __global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __restrict__ stages, int nstages,
                                                              int t_uniform, const long long* tptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x4 wreg[2][WREG];
+  f32x4 wreg[3][WREG];
   const int z = blockIdx.z, tid = threadIdx.x;
   const int skey = (nstages < 48 ? nstages : 47) * 2 + (gridDim.z - 1);
   (void)skey;
-  wfirst(stages[0], z, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, wreg[0]);
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DV dv, dvn;
+  dload(dv, stages, z, lane);
+  dvn = dv;
+  wprefetch(winfo_of(dv), wave, lane, wreg);
   for (int i = 0; i < nstages; ++i) {
-    const RStage& st = stages[i];
-    const RStage* nx = i + 1 < nstages ? &stages[i + 1] : nullptr;
-    const int b0 = blockIdx.x * st.g.S;
-    if (st.drain) drain_barrier();
-#define RC_ARGS st, nx, z, smem, tid, b0, t_uniform, tptr, wreg, skey, i
-    if (st.direct) {
-      if (st.NI == 1) rc_stage<1, 1, true>(RC_ARGS);
-      else rc_stage<1, 2, true>(RC_ARGS);
+    const bool has_next = i + 1 < nstages;
+    if (has_next) dload(dvn, stages + i + 1, z, lane);      // consumed a whole stage later
+    const int b0 = blockIdx.x * DG(S);
+    if (DS(drain)) drain_barrier();
+#define RC_ARGS dv, dvn, has_next, smem, tid, b0, t_uniform, tptr, wreg, skey, i
+    if (DIRECT) {
+      rc_stage<1, 1, true>(RC_ARGS);
     } else {
-      switch (st.MI * 4 + st.NI) {
+      switch (DS(MI) * 4 + DS(NI)) {
         case 1 * 4 + 1: rc_stage<1, 1, false>(RC_ARGS); break;
         case 2 * 4 + 1: rc_stage<2, 1, false>(RC_ARGS); break;
-        case 4 * 4 + 1: rc_stage<4, 1, false>(RC_ARGS); break;
         case 1 * 4 + 2: rc_stage<1, 2, false>(RC_ARGS); break;
-        case 2 * 4 + 2: rc_stage<2, 2, false>(RC_ARGS); break;
         default: break;
       }
     }
 #undef RC_ARGS
+    dv = dvn;
     lds_barrier();
 #ifdef TREBI_STAMPS
     { const int sidx = i; CSTAMP(6); }
@@ -831,18 +895,26 @@ __global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __res
 }
 
 bool chain_variant_ok(int MI, int NI) {
-  return (NI == 1 && (MI == 1 || MI == 2 || MI == 4)) || (NI == 2 && (MI == 1 || MI == 2));
+  return (NI == 1 && (MI == 1 || MI == 2)) || (NI == 2 && MI == 1);
 }
 
 hipError_t chain_init_device() {
-  return hipFuncSetAttribute((const void*)resident_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             160 * 1024);
+  hipError_t e = hipFuncSetAttribute((const void*)resident_chain_kernel<true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)resident_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  return e;
 }
 
-hipError_t launch_chain(const RStage* dev_stages, int nstages, int nz, int nblocks, size_t lds_bytes, int t_uniform,
-                        const long long* t, hipStream_t st) {
-  hipLaunchKernelGGL(resident_chain_kernel, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages, nstages,
-                     t_uniform, t);
+hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, size_t lds_bytes,
+                        int t_uniform, const long long* t, hipStream_t st) {
+  if (direct)
+    hipLaunchKernelGGL(resident_chain_kernel<true>, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages,
+                       nstages, t_uniform, t);
+  else
+    hipLaunchKernelGGL(resident_chain_kernel<false>, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages,
+                       nstages, t_uniform, t);
   return hipGetLastError();
 }
 

@@ -93,7 +93,6 @@ struct RStage {
   unsigned mLd4;                   // magic multiplier of ldD / 4
   int proRes, oPro;                // backward stage whose incoming gradient is resident (read-only) at oPro
   int direct;                      // no split-K: a wave owns a 16-row x (16*NI)-column tile and finishes it in registers
-  int pad_[2];
 };
 
 struct Tile {
@@ -109,7 +108,7 @@ ConvGeo conv_make_geo(const ConvP& p, const Tile& tl);
 bool conv_vec_ok(const ConvP& p);
 bool chain_variant_ok(int MI, int NI);
 hipError_t chain_init_device();
-hipError_t launch_chain(const RStage* dev_stages, int nstages, int nz, int nblocks, size_t lds_bytes,
+hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, size_t lds_bytes,
                         int t_uniform, const long long* t, hipStream_t st);
 
 // Value head (temporal.py:237-238) forward + the seed of the backward.

@@ -1022,7 +1022,7 @@ struct PlanStep {
   Tile tl{};
   HeadLaunch H{};
   int nz = 1;
-  int chain_off = 0, chain_n = 0, nblocks = 0;
+  int chain_off = 0, chain_n = 0, nblocks = 0, chain_direct = 0;
   size_t chain_lds = 0;
   double flops = 0;                // algorithmic, whole batch, all nets of the launch
   std::string name;
@@ -1051,7 +1051,7 @@ bool chain_tile(const Op& op, int S, int max_n, Tile* out, bool* direct) {
   };
   if (allow_direct && (op.Lout == 16 || op.Lout == 32)) {
     const int MS = S * op.Lout / 16;
-    bool ok = MS * NG <= 8;
+    bool ok = MS * NG <= 8 && NI == 1;
     if (op.gn) {
       const int gch = op.gnw.gch;
       ok = ok && op.Npad == op.N && op.N % GN_GROUPS == 0 &&
@@ -1090,6 +1090,7 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
     Tile tl;
     bool direct = false;
     if (!chain_tile(*o0[j], S, max_n, &tl, &direct)) break;
+    if (!directs.empty() && (bool)directs[0] != direct) break;      // one stage kind per launch
     tiles.push_back(tl);
     directs.push_back(direct);
     ++j;
@@ -1235,10 +1236,10 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
     }
     PlanStep ps;
     ps.kind = 2; ps.nz = nz;
-    ps.chain_off = (int)tab.size(); ps.chain_n = (int)n;
+    ps.chain_off = (int)tab.size(); ps.chain_n = (int)n; ps.chain_direct = directs[0];
     ps.nblocks = (B + S - 1) / S;
     ps.chain_lds = total * sizeof(float); ps.flops = fl;
-    ps.name = "chain[" + std::to_string(n) + "] S" + std::to_string(S) + " " + o0[i]->name + " .. " + o0[j - 1]->name;
+    ps.name = std::string(directs[0] ? "direct " : "") + "chain[" + std::to_string(n) + "] S" + std::to_string(S) + " " + o0[i]->name + " .. " + o0[j - 1]->name;
     tab.insert(tab.end(), run.begin(), run.end());
     plan.push_back(ps);
     return n;
@@ -1315,7 +1316,7 @@ int exec_plan(const Plan& plan, const RStage* dev_tab, int t_uniform, const long
       HIPCHK(hipEventRecord(prof->ev[prof->used].first, st));
     }
     if (ps.kind == 2) {
-      HIPCHK(launch_chain(dev_tab + ps.chain_off, ps.chain_n, ps.nz, ps.nblocks, ps.chain_lds, t_uniform, tptr, st));
+      HIPCHK(launch_chain(dev_tab + ps.chain_off, ps.chain_n, ps.chain_direct, ps.nz, ps.nblocks, ps.chain_lds, t_uniform, tptr, st));
     } else {
       ConvLaunch L = ps.L;
       for (int z = 0; z < ps.nz; ++z) { L.p[z].t = tptr; L.p[z].t_uniform = t_uniform; }
