@@ -69,6 +69,7 @@ struct WInfo {
   const float* w;
   int Npad, NG, KS, NI, chunk, KK, KK1, direct;
   unsigned mNG;
+  int n0;                          // first column of this workgroup's tile (single-layer launches)
 };
 // ---- stage descriptors live in VGPRs ---------------------------------------------------------------
 // Reading descriptor fields with scalar loads costs a scalar-cache round trip (hundreds of cycles) at
@@ -117,7 +118,7 @@ __device__ __forceinline__ T dfield(const DV& d) {
 
 __device__ __forceinline__ WInfo winfo_of(const DV& d) {
   return WInfo{DPF(d, w), DPF(d, Npad), DGF(d, NG), DGF(d, KS), DSF(d, NI), DGF(d, chunk), DGF(d, KK), DGF(d, KK1),
-               DSF(d, direct), DGF(d, mNG)};
+               DSF(d, direct), DGF(d, mNG), DSF(d, direct) ? (int)blockIdx.y * DGF(d, TN) : 0};
 }
 
 // Direct stages walk the reduction in blocks of up to WH = WREG/NI steps that never straddle the two
@@ -151,7 +152,7 @@ __device__ __forceinline__ void wblk(f32x4 (&w)[WREG], const float* pw, unsigned
 __device__ __forceinline__ void wprefetch(const WInfo& q, int wave, int lane, f32x4 (&w)[3][WREG]) {
   if (wave >= q.NG * q.KS) return;
   const int ks = FastDiv(q.NG, q.mNG).div(wave), ng = wave - ks * q.NG;
-  const unsigned wlane = (unsigned)(((lane >> 4) * q.Npad + ng * q.NI * 16 + (lane & 15)) * 4);
+  const unsigned wlane = (unsigned)(((lane >> 4) * q.Npad + q.n0 + ng * q.NI * 16 + (lane & 15)) * 4);
   const unsigned wstep = (unsigned)q.Npad * 16u;
   if (q.direct) {
     if (q.NI == 1) {
@@ -221,47 +222,61 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
   const int k_begin = (active && !DIRECT) ? ks * chunk : 0;
   const int k_end = active ? (DIRECT ? KK : ((k_begin + chunk < KK) ? k_begin + chunk : KK)) : 0;
   const int rowbase = DIRECT ? ks * 16 : 0;
-  const unsigned wlane = (unsigned)((g * Npad + ng * NI * 16 + lr) * 4);
+  const int n0 = DIRECT ? (int)blockIdx.y * TN : 0;          // column tile (single-layer launches; chains: 0)
+  const unsigned wlane = (unsigned)((g * Npad + n0 + ng * NI * 16 + lr) * 4);
   const unsigned wstep = (unsigned)Npad * 16u;
 
   // ---- phase A: everything this stage reads from global memory --------------------------------
   // GroupNorm-backward operands of this thread's team (registers): saved mish'(z)*gamma and xhat
   const int ts_pro = DG(ts_pro);
   const int pteam = ts_pro == 64 ? (tid >> 6) : (tid >> 4), ptl = tid & (ts_pro - 1);
+  const int pnteams = ts_pro == 64 ? (nthr >> 6) : (nthr >> 4);
+  // operands of GroupNorm-backward instance `inst` (candidate, group) for this lane: up to 2 float4 each
+  auto pro_fetch = [&](int inst, f32x4 (&gg)[2], f32x4 (&xx)[2], int (&po)[2], int (&pi)[2], float& rs) -> bool {
+    po[0] = po[1] = -1;
+    pi[0] = pi[1] = 0;
+    const int s = inst >> 3, gi = inst & 7;
+    if (inst >= S * GN_GROUPS || s >= nvs) return false;
+    const int gch = DP(pro_gch), pg4 = DG(pgch4), cnt4 = DG(pcnt4);
+    const FastDiv dG(pg4, DG(mPGch4));
+    rs = gld(DP(pro_stats) + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2 + 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = ptl + j * ts_pro;
+      if (e < cnt4) {
+        const int li = dG.div(e), c = gi * gch + 4 * (e - li * pg4);
+        po[j] = (s * Rb + DS(pr0) + li) * ldA + c;
+        pi[j] = DS(proRes) ? (s * (Lin + 4) + 2 + li) * ldA + c : po[j];
+        const unsigned go = ((unsigned)(b0 + s) * Lin + li) * (unsigned)Cin + c;
+        gg[j] = gld4(DP(pro_g) + go);
+        xx[j] = gld4(DP(pro_y) + go);
+      }
+    }
+    return true;
+  };
   f32x4 pg_[2], px_[2];
   int po_[2] = {-1, -1}, pi_[2] = {0, 0};
   float prstd = 0.f;
   bool pinst = false;
-  if (haspro && active) {
-    const int inst = pteam;                          // host guarantees S*8 <= number of teams
-    const int s = inst >> 3, gi = inst & 7;
-    if (inst < S * GN_GROUPS && s < nvs) {
-      pinst = true;
-      const int gch = DP(pro_gch), pg4 = DG(pgch4), cnt4 = DG(pcnt4);
-      const FastDiv dG(pg4, DG(mPGch4));
-      prstd = gld(DP(pro_stats) + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2 + 1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int e = ptl + j * ts_pro;
-        if (e < cnt4) {
-          const int li = dG.div(e), c = gi * gch + 4 * (e - li * pg4);
-          po_[j] = (s * Rb + DS(pr0) + li) * ldA + c;
-          pi_[j] = DS(proRes) ? (s * (Lin + 4) + 2 + li) * ldA + c : po_[j];
-          const unsigned go = ((unsigned)(b0 + s) * Lin + li) * (unsigned)Cin + c;
-          pg_[j] = gld4(DP(pro_g) + go);
-          px_[j] = gld4(DP(pro_y) + go);
-        }
-      }
-    }
-  }
+  if (haspro && active) pinst = pro_fetch(pteam, pg_, px_, po_, pi_, prstd);   // first instance: latency overlaps staging
+  CSTAMP(8);
   // per-column parameters and time-bias rows: requested now, parked in registers, written to LDS after the K
   // loop (consuming a load here would also wait for the previous stage's stores: vmcnt retires in order).
   // Direct stages: a lane's accumulators all sit in one column per sub-tile, so the parameters simply stay
   // in that lane's registers.
   float c0 = 0.f, c1 = 1.f, c2 = 0.f, c3 = 0.f;
   float tbv[2] = {0.f, 0.f};
-  float dbias[NI], dgam[NI], dbet[NI], dbi2[NI], dtb[NI];
-  const int sw = DIRECT ? (int)dLout.div(rowbase) : 0;        // direct: the candidate of this wave's 16 rows
+  float dbias[NI], dgam[NI], dbet[NI], dbi2[NI], dtb[NI][4];
+  // direct: rows 4*g + q of the wave's 16-row tile -> (candidate, position)
+  int sq[4], loq[4];
+  bool vq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = rowbase + 4 * g + q;
+    sq[q] = dLout.div(r);
+    loq[q] = r - sq[q] * Lout;
+    vq[q] = DIRECT && active && sq[q] < nvs;
+  }
   const bool colt = !DIRECT && active && tid < TN;
   auto tb_load = [&](int e) -> float {
     int s = dTN.div(e), c = e - s * TN;
@@ -272,20 +287,25 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
   };
   if (active) {
     if (DIRECT) {
-      long long tt = 0;
-      if (hastb) {
-        tt = t_uniform >= 0 ? t_uniform : (sw < nvs ? gldll(tptr + b0 + sw) : 0);
-        tt = tt < 0 ? 0 : (tt >= DP(T) ? DP(T) - 1 : tt);
-      }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        const int n = (ng * NI + ni) * 16 + lr;
+        const int n = n0 + (ng * NI + ni) * 16 + lr;
         const bool ok = n < N;
         dbias[ni] = (ok && DP(bias)) ? gld(DP(bias) + n) : 0.f;
         dgam[ni] = (ok && hasgn) ? gld(DP(gamma) + n) : 1.f;
         dbet[ni] = (ok && hasgn) ? gld(DP(beta) + n) : 0.f;
         dbi2[ni] = (ok && DP(bias2)) ? gld(DP(bias2) + n) : 0.f;
-        dtb[ni] = (ok && hastb) ? gld(DP(tbias) + (unsigned)tt * (unsigned)N + n) : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          dtb[ni][q] = 0.f;
+          if (ok && hastb && (q == 0 || (t_uniform < 0 && Lout < 4))) {       // one time row per candidate
+            long long tt = t_uniform >= 0 ? t_uniform : (sq[q] < nvs ? gldll(tptr + b0 + sq[q]) : 0);
+            tt = tt < 0 ? 0 : (tt >= DP(T) ? DP(T) - 1 : tt);
+            dtb[ni][q] = gld(DP(tbias) + (unsigned)tt * (unsigned)N + n);
+          } else if (q > 0) {
+            dtb[ni][q] = dtb[ni][0];
+          }
+        }
       }
     }
     if (colt) {
@@ -300,14 +320,15 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
       for (int u = 0; u < 2; ++u)
         if (tid + u * nthr < S * TN) tbv[u] = tb_load(tid + u * nthr);
     }
+    CSTAMP(9);
     // identity residual from global memory -> tile [TM][TNp]
     if (hasres && !DS(resRes)) {
       const int nRes4 = DG(nRes4);
       for (int e = tid; e < nRes4; e += nthr) {
         int row = dTN4.div(e), c4 = e - row * DG(tn4);
-        int left = N - 4 * c4;
+        int left = N - n0 - 4 * c4;
         if (row >= nvs * Lout) left = 0;
-        const float* sp = DP(res) + ((unsigned)b0 * Lout + row) * (unsigned)DP(ldres) + 4 * c4;
+        const float* sp = DP(res) + ((unsigned)b0 * Lout + row) * (unsigned)DP(ldres) + n0 + 4 * c4;
         *(f32x4*)&resb[row * TNp + 4 * c4] = DG(vecr) ? load4<true>(sp, left) : load4<false>(sp, left);
       }
     }
@@ -368,6 +389,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
           if (so[u] >= 0) *(f32x4*)&slab2[so[u]] = v[u];
       }
     }
+    CSTAMP(10);
     // zero halo rows of the resident destination (2 in front, 2 behind every candidate)
     if (DS(dstRes)) {
       const int ld4n = DS(ldD) >> 2, tot = S * 4 * ld4n;
@@ -389,23 +411,26 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
   // next layer reads it again); dY always lands in the slab the K loop reads.
   if (haspro) {
     const float* pin = smem + (DS(proRes) ? DS(oPro) : DS(oSrc));
-    if (active && pteam < S * GN_GROUPS) {
-      f32x4 d[2];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (pinst && po_[j] >= 0) {
-          d[j] = *(const f32x4*)&pin[pi_[j]] * pg_[j];
-          s1 += hsum(d[j]);
-          s2 += hsum(d[j] * px_[j]);
-        }
-      }
+    if (active) {
       const float icnt = 1.f / (float)(DG(pcnt4) * 4);
-      const float m1 = team_sum(s1, ts_pro) * icnt, m2 = team_sum(s2, ts_pro) * icnt;
+      for (int inst = pteam; inst < S * GN_GROUPS; inst += pnteams) {
+        if (inst != pteam) pinst = pro_fetch(inst, pg_, px_, po_, pi_, prstd);
+        f32x4 d[2];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (pinst && po_[j] >= 0) *(f32x4*)&slab[po_[j]] = (d[j] - m1 - px_[j] * m2) * prstd;
+        for (int j = 0; j < 2; ++j) {
+          d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (pinst && po_[j] >= 0) {
+            d[j] = *(const f32x4*)&pin[pi_[j]] * pg_[j];
+            s1 += hsum(d[j]);
+            s2 += hsum(d[j] * px_[j]);
+          }
+        }
+        const float m1 = team_sum(s1, ts_pro) * icnt, m2 = team_sum(s2, ts_pro) * icnt;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (pinst && po_[j] >= 0) *(f32x4*)&slab[po_[j]] = (d[j] - m1 - px_[j] * m2) * prstd;
+      }
     }
     lds_barrier();
   }
@@ -427,7 +452,8 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
     // block are requested from LDS before its first MFMA -- with one or two waves per SIMD nothing else
     // hides the LDS latency -- and the weights of the next block travel meanwhile.
     const int r = rowbase + lr;
-    const int s = dLout.div(r), lo = r - s * Lout;
+    int s = dLout.div(r), lo = r - s * Lout;
+    if (s >= S) { s = 0; lo = 0; }                    // rows past the last candidate: any valid address
     const int offA = DS(oSrc) + (s * Rb + lo * stride + a0) * ldA + 4 * g;
     const int off2 = DS(o2) + (s * Rb2 + h2 + lo) * ld2 + 4 * g;
     constexpr int SH = NI == 1 ? 3 : 2;
@@ -552,7 +578,6 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
         }
       }
     };
-    CSTAMP(8);
     for (int kb = k_begin; kb < k_end; kb += 2 * WH) {
       const bool more = kb + WH < k_end;
       if (more) wload(wreg[1], pw, wstep, wlane, NI, kb + WH, k_end);
@@ -607,62 +632,73 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
     const unsigned ldo = DP(ldo);
     const int RbR = DS(RbR), hR = DS(hR), ldR = DS(ldR), RbD = DS(RbD), ldD = DS(ldD);
     const bool dstRes = DS(dstRes) != 0;
-    const int lo0 = rowbase - sw * Lout + 4 * g;
-    const bool live = active && sw < nvs;
-    const bool two = Lout > 16;
-    float v[NI][4], ml[NI], m2[NI];
+    // Rows 4*g + q of the tile map to (candidate sq[q], position loq[q]).  A (candidate, group) lives in one
+    // wave -- reduced over q, the group's lanes of a row (DPP) and the lane groups g that share the candidate
+    // -- except for two cases that need ONE exchange of (mean, M2) with a partner wave through LDS: Lout == 32
+    // (the candidate spans two row tiles) and gch == 32 (the group spans two 16-column tiles).
+    const int gch = DP(gch);
+    const bool two = Lout > 16, twoc = gch > 16;
+    const bool xchg = hasgn && (two || twoc);
+    float v[NI][4], ml[NI][4], m2[NI][4];
     int cols[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      cols[ni] = (ng * NI + ni) * 16 + lr;
-      ml[ni] = 0.f;
-      m2[ni] = 0.f;
+      cols[ni] = n0 + (ng * NI + ni) * 16 + lr;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[ni][q] = acc[0][ni][q] + dbias[ni];
-    }
-    float* xch = red;                                  // [wave][NI][16][2]
-    const int gch = DP(gch);
-    if (hasgn && active) {
-      const int rl = gch < 16 ? gch : 16;              // lanes of a 16-lane row that share a group
-      const bool both = NI == 2 && gch > 16;           // the group spans both sub-tiles of the wave
-      const float inl = 1.f / (float)(16 * gch);
-      float s1[NI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) s1[ni] = (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
-      if (both) s1[0] = s1[NI - 1] = s1[0] + s1[NI - 1];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        float t = row_sum(s1[ni], rl);
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        ml[ni] = t * inl;
+      for (int q = 0; q < 4; ++q) {
+        v[ni][q] = acc[0][ni][q] + dbias[ni];
+        ml[ni][q] = 0.f;
+        m2[ni][q] = 0.f;
       }
-      float s2[NI];
+    }
+    float* xch = red;                                  // [wave][NI][64][2]
+    const int lrows = Lout < 16 ? Lout : 16;           // rows of a candidate inside this wave's tile
+    const int gl = gch < 16 ? gch : 16;                // columns of a group inside a 16-column tile
+    if (hasgn && active) {
+      const float inl = 1.f / (float)(lrows * gl);
+      // per-q partials -> per-q totals over this wave's part of the (candidate, group)
+      auto reduce = [&](float (&t)[4]) {
+        if (Lout >= 4) {
+          float u = (t[0] + t[1]) + (t[2] + t[3]);
+          u = row_sum(u, gl);
+          if (Lout >= 8) u += __shfl_xor(u, 16, 64);
+          if (Lout >= 16) u += __shfl_xor(u, 32, 64);
+          t[0] = t[1] = t[2] = t[3] = u;
+        } else if (Lout == 2) {
+          float a = row_sum(t[0] + t[1], gl), b = row_sum(t[2] + t[3], gl);
+          t[0] = t[1] = a;
+          t[2] = t[3] = b;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[q] = row_sum(t[q], gl);
+        }
+      };
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        s2[ni] = 0.f;
+        float t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = v[ni][q];
+        reduce(t);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float d = v[ni][q] - ml[ni];
-          s2[ni] += d * d;
+          ml[ni][q] = t[q] * inl;
+          const float d = v[ni][q] - ml[ni][q];
+          t[q] = d * d;
         }
-      }
-      if (both) s2[0] = s2[NI - 1] = s2[0] + s2[NI - 1];
+        reduce(t);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        float t = row_sum(s2[ni], rl);
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        m2[ni] = t;
-        if (two && g == 0) {
-          float* o = xch + ((wave * NI + ni) * 16 + lr) * 2;
-          o[0] = ml[ni];
-          o[1] = t;
+        for (int q = 0; q < 4; ++q) m2[ni][q] = t[q];
+        if (xchg) {
+          float* o = xch + ((wave * NI + ni) * 64 + lane) * 2;
+          o[0] = ml[ni][0];
+          o[1] = m2[ni][0];
         }
       }
     }
-    if (hasgn && two) lds_barrier();
-    if (live) {
+    CSTAMP(11);
+    if (xchg) lds_barrier();
+    CSTAMP(12);
+    if (active) {
       const FastDiv dG(DG(gch4), DG(mGch4));
       float* sy = DP(save_y);
       float* sg = DP(save_g);
@@ -674,31 +710,32 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
           ph = dOs.div(col);
           ch = col - ph * osplit;
         }
-        float mean = ml[ni], rstd = 0.f;
-        if (hasgn) {
-          float M2 = m2[ni], cnt = (float)(16 * gch);
-          if (two) {
-            const int pwv = (ks & 1) ? wave - NG : wave + NG;
-            const float* o = xch + ((pwv * NI + ni) * 16 + lr) * 2;
-            const float mp = o[0], m2p = o[1];
-            const float dlt = mean - mp;
-            M2 = M2 + m2p + dlt * dlt * (0.5f * cnt);
-            mean = 0.5f * (mean + mp);
-            cnt *= 2.f;
-          }
-          rstd = __frsqrt_rn(M2 / cnt + GN_EPS);
-          const int gi = dG.div(col >> 2);
-          if (DP(save_stats) && g == 0 && (col & (gch - 1)) == 0 && (!two || (ks & 1) == 0)) {
-            float* o = DP(save_stats) + ((unsigned)(b0 + sw) * GN_GROUPS + gi) * 2;
-            gst(o, mean);
-            gst(o + 1, rstd);
-          }
-        }
+        float mean = 0.f, rstd = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int lo = lo0 + q;
+          if (hasgn && (q == 0 || Lout < 4)) {
+            float M2 = m2[ni][q], cnt = (float)(lrows * gl);
+            mean = ml[ni][q];
+            if (xchg) {                                  // Chan's combination of two equal-sized parts
+              const int pwv = two ? ((ks & 1) ? wave - NG : wave + NG) : (wave ^ 1);
+              const float* o = xch + ((pwv * NI + ni) * 64 + lane) * 2;
+              const float mp = o[0], m2p = o[1];
+              const float dlt = mean - mp;
+              M2 = M2 + m2p + dlt * dlt * (0.5f * cnt);
+              mean = 0.5f * (mean + mp);
+              cnt *= 2.f;
+            }
+            rstd = __frsqrt_rn(M2 / cnt + GN_EPS);
+          }
+          if (!vq[q]) continue;
+          const int sw = sq[q], lo = loq[q];
           float val = v[ni][q];
           if (hasgn) {
+            if (DP(save_stats) && lo == 0 && (col & (gch - 1)) == 0) {
+              float* o = DP(save_stats) + ((unsigned)(b0 + sw) * GN_GROUPS + dG.div(col >> 2)) * 2;
+              gst(o, mean);
+              gst(o + 1, rstd);
+            }
             const float xh = (val - mean) * rstd;
             float a, b;
             mish_both(xh * dgam[ni] + dbet[ni], &a, &b);
@@ -709,9 +746,9 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
             }
             val = a;
           }
-          val += dtb[ni];
+          val += dtb[ni][q];
           if (has2) val += acc2[0][ni][q] + dbi2[ni];
-          if (hasres) val += resb[(sw * RbR + hR + lo) * ldR + col];
+          if (hasres) val += resb[(sw * RbR + hR + lo) * ldR + col - n0];
           const int pos = osplit > 0 ? 2 * lo + ph : lo;
           if (dstRes) dreg[(sw * RbD + 2 + pos) * ldD + ch] = val;
           if (pout && col < N) {
@@ -797,9 +834,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
           sum += hsum(a);
         }
       }
-      CSTAMP(9);
       const float mean = team_sum(sum, ts) * icnt;
-      CSTAMP(10);
       float sq = 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -808,7 +843,6 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
           sq += hsum(d * d);
         }
       const float rstd = 1.f / sqrtf(team_sum(sq, ts) * icnt + GN_EPS);
-      CSTAMP(11);
       if (tl == 0 && DP(save_stats)) {
         float* o = DP(save_stats) + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2;
         gst(o, mean);
@@ -829,7 +863,6 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
             m[q] = a;
             dm[q] = b;
           }
-          CSTAMP(12 + j);
           if (sy) {
             unsigned so = ((unsigned)b0 * Lout + s * Lout + lo_[j]) * (unsigned)N + col;
             gst4(sy + so, xh);
@@ -907,10 +940,10 @@ hipError_t chain_init_device() {
   return e;
 }
 
-hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, size_t lds_bytes,
+hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, int ny, size_t lds_bytes,
                         int t_uniform, const long long* t, hipStream_t st) {
   if (direct)
-    hipLaunchKernelGGL(resident_chain_kernel<true>, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages,
+    hipLaunchKernelGGL(resident_chain_kernel<true>, dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,
                        nstages, t_uniform, t);
   else
     hipLaunchKernelGGL(resident_chain_kernel<false>, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages,

@@ -108,7 +108,7 @@ ConvGeo conv_make_geo(const ConvP& p, const Tile& tl);
 bool conv_vec_ok(const ConvP& p);
 bool chain_variant_ok(int MI, int NI);
 hipError_t chain_init_device();
-hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, size_t lds_bytes,
+hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, int ny, size_t lds_bytes,
                         int t_uniform, const long long* t, hipStream_t st);
 
 // Value head (temporal.py:237-238) forward + the seed of the backward.

@@ -1022,7 +1022,7 @@ struct PlanStep {
   Tile tl{};
   HeadLaunch H{};
   int nz = 1;
-  int chain_off = 0, chain_n = 0, nblocks = 0, chain_direct = 0;
+  int chain_off = 0, chain_n = 0, nblocks = 0, chain_direct = 0, ny = 1;
   size_t chain_lds = 0;
   double flops = 0;                // algorithmic, whole batch, all nets of the launch
   std::string name;
@@ -1049,15 +1049,23 @@ bool chain_tile(const Op& op, int S, int max_n, Tile* out, bool* direct) {
     const int ts = (S * GN_GROUPS * 4 <= nteams16) ? 64 : 16;
     return op.Lin * (op.pro_gn.gch / 4) <= 2 * ts && S * GN_GROUPS <= 16 * nteams16 / ts;
   };
-  if (allow_direct && (op.Lout == 16 || op.Lout == 32)) {
-    const int MS = S * op.Lout / 16;
-    bool ok = MS * NG <= 8 && NI == 1;
+  const int L = op.Lout;
+  const bool lpow2 = L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32;
+  if (allow_direct && lpow2 && NI == 1) {
+    const int MS = (S * L + 15) / 16;
+    bool ok = MS * NG <= 8 && (L >= 16 || S * L <= 16 || (S * L) % 16 == 0);
     if (op.gn) {
       const int gch = op.gnw.gch;
-      ok = ok && op.Npad == op.N && op.N % GN_GROUPS == 0 &&
-           ((NI == 1 && (gch == 4 || gch == 8 || gch == 16)) || (NI == 2 && gch == 32));
+      const bool two = L == 32, twoc = gch == 32;
+      ok = ok && op.Npad == op.N && op.N % GN_GROUPS == 0 && (gch == 4 || gch == 8 || gch == 16 || gch == 32) &&
+           !(twoc && (two || L < 4 || NG % 2));
     }
-    if (ok && pro_ok(4 * NG * MS)) {
+    if (op.pro) {
+      const int ts = (S * GN_GROUPS * 4 <= 4 * NG * MS) ? 64 : 16;
+      ok = ok && op.stride == 1 && op.Lin == op.Lout && op.pro_gn.gch % 4 == 0 && op.Cin % 16 == 0 &&
+           op.Lin * (op.pro_gn.gch / 4) <= 2 * ts;
+    }
+    if (ok) {
       *out = Tile{MS, NI, NG, MS, S};                 // MI = KS = row tiles: TM = 16*MS, 64*NG*MS threads
       *direct = true;
       return true;
@@ -1210,7 +1218,7 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
       if (op.Cin2_p && !have_2) slab2sz = std::max(slab2sz, (size_t)S * op.Lout * G.ld2);
       if (op.res.id != NONE && !have_r) restsz = std::max(restsz, (size_t)G.TM * G.TNp);
       if (st.direct) {
-        redsz = std::max(redsz, (size_t)8 * 2 * 16 * 2);       // (mean, M2) exchange between row-tile waves
+        redsz = std::max(redsz, (size_t)8 * 64 * 2);           // (mean, M2) exchange between partner waves
       } else {
         redsz = std::max(redsz, (size_t)G.red1);
         if (op.Cin2_p) red2sz = std::max(red2sz, (size_t)G.red1);
@@ -1247,6 +1255,67 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
   return 0;
 }
 
+// A single layer as a one-stage direct launch: workgroups own MS row tiles x NG column tiles of 16x16,
+// one wave per tile over the whole reduction, grid = (candidate groups, column tiles, nets).
+bool plan_direct_single(const Op& op, const Op* op1, const Resolver& r0, const Resolver* r1, int B,
+                        std::vector<RStage>& tab, Plan& plan) {
+  static const bool allow = getenv("TREBI_DIRECT_SINGLE") && atoi(getenv("TREBI_DIRECT_SINGLE")) != 0;   // experimental: the split-K kernel is still faster for wide layers
+  static const int max_b = getenv("TREBI_DIRECT_MAXB") ? atoi(getenv("TREBI_DIRECT_MAXB")) : 256;
+  if (!allow || B > max_b || op.kind != 0 || op.Npad % 16) return false;
+  const int nz = r1 ? 2 : 1;
+  const int L = op.Lout, units = op.Npad / 16;
+  if (!(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32)) return false;
+  if (op.osplit && op.osplit % 16) return false;
+  const int gch = op.gn ? op.gnw.gch : 0;
+  const bool two = L == 32, twoc = gch == 32;
+  if (op.gn && (op.Npad != op.N || op.N % GN_GROUPS || !(gch == 4 || gch == 8 || gch == 16 || gch == 32))) return false;
+  if (twoc && (two || L < 4 || units % 2)) return false;
+  const int S = L >= 16 ? 1 : 16 / L;
+  const int MS = (S * L + 15) / 16;
+  int NG = 1;
+  for (int c : {2, 4, 8})
+    if (units % c == 0 && c * MS <= 8 && c <= 4) NG = c;
+  if (twoc && NG % 2) return false;
+  if (op.pro) {
+    const int ts = (S * GN_GROUPS * 4 <= 4 * NG * MS) ? 64 : 16;
+    if (op.stride != 1 || op.Lin != op.Lout || op.pro_gn.gch % 4 || op.Cin % 16 || op.Lin * (op.pro_gn.gch / 4) > 2 * ts)
+      return false;
+  }
+  RStage st{};
+  st.p[0] = r0.conv(op);
+  if (r1) st.p[1] = r1->conv(*op1);
+  if (!st.p[0].x || !st.p[0].out) return false;
+  const Tile tl{MS, 1, NG, MS, S};
+  st.MI = MS; st.NI = 1; st.direct = 1;
+  st.vec = conv_vec_ok(st.p[0]) && (!r1 || conv_vec_ok(st.p[1]));
+  if (op.pro && !st.vec) return false;
+  st.g = conv_make_geo(st.p[0], tl);
+  const ConvGeo& G = st.g;
+  auto r4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
+  const size_t slab = r4((size_t)S * G.R * G.ldA), slab2 = op.Cin2_p ? r4((size_t)S * op.Lout * G.ld2) : 0,
+               rest = op.res.id != NONE ? r4((size_t)G.TM * G.TNp) : 0, xch = 8 * 64 * 2;
+  st.srcRes = 0; st.oSrc = 0; st.Rb = G.R; st.a0 = 0; st.pr0 = G.fh;
+  st.x2Res = 0; st.o2 = (int)slab; st.Rb2 = op.Lout; st.h2 = 0;
+  st.resRes = 0; st.oR = (int)(slab + slab2); st.RbR = op.Lout; st.hR = 0; st.ldR = G.TNp;
+  st.dstRes = 0; st.oD = 0; st.RbD = 1; st.ldD = 4; st.Ld = 0; st.mLd4 = 0;
+  st.oRed = (int)(slab + slab2 + rest); st.oRed2 = st.oRed; st.oColp = st.oRed; st.oTb = st.oRed;
+  const size_t total = slab + slab2 + rest + xch;
+  if (total * sizeof(float) > 160 * 1024) return false;
+  PlanStep ps;
+  ps.kind = 2; ps.nz = nz;
+  ps.chain_off = (int)tab.size(); ps.chain_n = 1; ps.chain_direct = 1;
+  ps.nblocks = (B + S - 1) / S;
+  ps.ny = op.Npad / (16 * NG);
+  ps.chain_lds = total * sizeof(float);
+  ps.flops = op.flops * B * nz;
+  char tb[96];
+  snprintf(tb, sizeof tb, " direct MS%d NG%d S%d grid %dx%d", MS, NG, S, ps.nblocks, ps.ny);
+  ps.name = op.name + (op.pro ? " (bwd)" : "") + tb;
+  tab.push_back(st);
+  plan.push_back(ps);
+  return true;
+}
+
 int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vector<const std::vector<Op>*>& lists1,
                const Resolver& r0, const Resolver* r1, int B, bool want_grad, int chain_S, int chain_max_n,
                std::vector<RStage>& tab, Plan& plan) {
@@ -1271,6 +1340,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
       size_t n = plan_chain(o0, o1, i, r0, r1, B, chain_S, chain_max_n, tab, plan);
       if (n) { i += n; continue; }
     }
+    if (plan_direct_single(op, r1 ? o1[i] : nullptr, r0, r1, B, tab, plan)) { ++i; continue; }
     PlanStep st;
     st.kind = 0; st.nz = nz;
     st.L.p[0] = r0.conv(op);
@@ -1316,7 +1386,7 @@ int exec_plan(const Plan& plan, const RStage* dev_tab, int t_uniform, const long
       HIPCHK(hipEventRecord(prof->ev[prof->used].first, st));
     }
     if (ps.kind == 2) {
-      HIPCHK(launch_chain(dev_tab + ps.chain_off, ps.chain_n, ps.chain_direct, ps.nz, ps.nblocks, ps.chain_lds, t_uniform, tptr, st));
+      HIPCHK(launch_chain(dev_tab + ps.chain_off, ps.chain_n, ps.chain_direct, ps.nz, ps.nblocks, ps.ny, ps.chain_lds, t_uniform, tptr, st));
     } else {
       ConvLaunch L = ps.L;
       for (int z = 0; z < ps.nz; ++z) { L.p[z].t = tptr; L.p[z].t_uniform = t_uniform; }

@@ -31,4 +31,4 @@ for key in range(96):
         for i in range(ns):
             s = a[key, i]
             d = [s[k + 1] - s[k] for k in range(6)]
-            print(f'{i:3d}', ' '.join(f'{x:6d}' for x in d), '|', s[6] - s[0], '| pins', s[7] - s[0], '| k-setup', s[8] - s[2], '| epi: partial-sum', s[9] - s[4], 'mean', s[10] - s[9], 'rstd', s[11] - s[10], 'mish0', s[12] - s[11], 'fin0+mish1', s[13] - s[12], 'fin1', s[5] - s[13])
+            print(f'{i:3d}', ' '.join(f'{x:6d}' for x in d), '|', s[6] - s[0], '| A: pins', s[7] - s[0], 'pro-ld', s[8] - s[7], 'col-ld', s[9] - s[8], 'stage', s[10] - s[9], 'halo', s[1] - s[10], '| epi: stats', s[11] - s[4], 'xbar', s[12] - s[11], 'rest', s[5] - s[12])
