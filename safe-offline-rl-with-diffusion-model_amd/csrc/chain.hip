@@ -82,7 +82,6 @@ constexpr int TAIL0 = (int)offsetof(RStage, g);
 constexpr int VIEW_DW = PW + (int)((sizeof(RStage) - TAIL0) / 4);
 static_assert(VIEW_DW <= 256, "descriptor view must fit 4 VGPRs");
 static_assert(sizeof(ConvP) % 4 == 0 && TAIL0 % 4 == 0 && sizeof(RStage) % 4 == 0, "dword layout");
-struct DV { unsigned v[4]; };
 __device__ __forceinline__ void dload(DV& d, const RStage* st, int z, int lane) {
   const unsigned* base = (const unsigned*)st;
 #pragma unroll
@@ -90,23 +89,6 @@ __device__ __forceinline__ void dload(DV& d, const RStage* st, int z, int lane) 
     const int j = lane + 64 * k;
     const int src = j < PW ? z * PW + j : TAIL0 / 4 + (j - PW);
     d.v[k] = j < VIEW_DW ? *(const TREBI_GLOBAL unsigned*)(base + src) : 0u;
-  }
-}
-template <int IDX>
-__device__ __forceinline__ unsigned dget(const DV& d) {
-  return (unsigned)__builtin_amdgcn_readlane((int)d.v[IDX >> 6], IDX & 63);
-}
-template <typename T, int IDX>
-__device__ __forceinline__ T dfield(const DV& d) {
-  if constexpr (sizeof(T) == 4) {
-    union { unsigned u; T t; } c;
-    c.u = dget<IDX>(d);
-    return c.t;
-  } else {
-    static_assert(sizeof(T) == 8, "descriptor fields are 4 or 8 bytes");
-    union { unsigned long long u; T t; } c;
-    c.u = (unsigned long long)dget<IDX>(d) | ((unsigned long long)dget<IDX + 1>(d) << 32);
-    return c.t;
   }
 }
 #define DPF(d, f) dfield<decltype(ConvP::f), (int)(offsetof(ConvP, f) / 4)>(d)

@@ -100,33 +100,42 @@ size_t conv_lds_bytes(const ConvP& p, const Tile& tl) {
 }
 
 // WB = reduction steps whose weights a wave preloads into registers before anything else.
+// The launch descriptor (this net's ConvP followed by the ConvGeo) is read ONCE from the kernel-argument
+// segment with vector loads, one dword per lane, and kept in 4 VGPRs (see DV in device_util.h).
+constexpr int CPW = (int)(sizeof(ConvP) / 4);
+constexpr int CG0 = (int)offsetof(ConvLaunch, g);
+constexpr int CVIEW_DW = CPW + (int)(sizeof(ConvGeo) / 4);
+static_assert(CVIEW_DW <= 256 && sizeof(ConvP) % 4 == 0 && CG0 % 4 == 0, "launch descriptor view must fit 4 VGPRs");
+#define CP(f) dfield<decltype(ConvP::f), (int)(offsetof(ConvP, f) / 4)>(dv)
+#define CG(f) dfield<decltype(ConvGeo::f), CPW + (int)(offsetof(ConvGeo, f) / 4)>(dv)
+
 template <int MI, int NI, bool VEC>
-__device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, float* smem, const int b0, const int n0,
+__device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b0, const int n0,
                                           const int tid, int t_uniform, const long long* tptr) {
   constexpr int WB = (NI == 1) ? (MI <= 2 ? 24 : 16) : 8;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // ---- every argument field used below, read once and pinned in scalar registers ----------------
-  const float* px = p.x;  const float* pw = p.w;  float* pout = p.out;
-  int ldx = p.ldx, Cin = p.Cin, Lin = p.Lin, Lout = p.Lout, stride = p.stride, B = p.B, N = p.N, Npad = p.Npad;
-  int S = G.S, NG = G.NG, KS = G.KS, nthr = G.nthr, TM = G.TM, TN = G.TN, TNp = G.TNp, R = G.R, ldA = G.ldA,
-      ld2 = G.ld2;
-  int cbpt = G.cbpt, KK1 = G.KK1, KK = G.KK, chunk = G.chunk, nv = G.nv, fh = G.fh;
+  const float* px = CP(x);  const float* pw = CP(w);  float* pout = CP(out);
+  int ldx = CP(ldx), Cin = CP(Cin), Lin = CP(Lin), Lout = CP(Lout), stride = CP(stride), B = CP(B), N = CP(N), Npad = CP(Npad);
+  int S = CG(S), NG = CG(NG), KS = CG(KS), nthr = CG(nthr), TM = CG(TM), TN = CG(TN), TNp = CG(TNp), R = CG(R), ldA = CG(ldA),
+      ld2 = CG(ld2);
+  int cbpt = CG(cbpt), KK1 = CG(KK1), KK = CG(KK), chunk = CG(chunk), nv = CG(nv), fh = CG(fh);
   PIN(px); PIN(pw); PIN(pout); PIN(ldx); PIN(Cin); PIN(Lin); PIN(Lout); PIN(stride); PIN(B); PIN(N); PIN(Npad);
   PIN(S); PIN(NG); PIN(KS); PIN(nthr); PIN(TM); PIN(TN); PIN(TNp); PIN(R); PIN(ldA); PIN(ld2);
   PIN(cbpt); PIN(KK1); PIN(KK); PIN(chunk); PIN(nv); PIN(fh);
-  const bool has2 = p.x2 != nullptr, haspro = p.pro != 0, hasres = p.res != nullptr, hastb = p.tbias != nullptr,
-             hasgn = p.gn != 0;
+  const bool has2 = CP(x2) != nullptr, haspro = CP(pro) != 0, hasres = CP(res) != nullptr, hastb = CP(tbias) != nullptr,
+             hasgn = CP(gn) != 0;
   const bool active = tid < nthr;
   float* slab = smem;
-  float* slab2 = smem + G.oSlab2;
-  float* yslab = smem + G.oY;
-  float* restile = smem + G.oRes;
-  float* colp = smem + G.oColp;          // [4][TN]: bias, gamma, beta, bias2
-  float* tbrow = smem + G.oTb;           // [S][TN]
-  float* pstat = smem + G.oPstat;        // [S*8][2] mean, rstd of the producing block
-  const FastDiv dLout(Lout, G.mLout), dTN4(G.tn4, G.mTN4), dTN(TN, G.mTN);
+  float* slab2 = smem + CG(oSlab2);
+  float* yslab = smem + CG(oY);
+  float* restile = smem + CG(oRes);
+  float* colp = smem + CG(oColp);          // [4][TN]: bias, gamma, beta, bias2
+  float* tbrow = smem + CG(oTb);           // [S][TN]
+  float* pstat = smem + CG(oPstat);        // [S*8][2] mean, rstd of the producing block
+  const FastDiv dLout(Lout, CG(mLout)), dTN4(CG(tn4), CG(mTN4)), dTN(TN, CG(mTN));
   const int nvs = (B - b0 < S) ? B - b0 : S;       // candidates of this tile that exist
   STAMP(0);
 
@@ -135,7 +144,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
   // reduction index is permuted so that lane-group g = l>>4 owns channels 16*kk+4g .. +3 of
   // step kk and the four MFMAs of the step consume one float4 of A (LDS) and one of B (global).
   const int g = lane >> 4, lr = lane & 15;
-  const int ks = FastDiv(NG, G.mNG).div(wave), ng = wave - ks * NG;
+  const int ks = FastDiv(NG, CG(mNG)).div(wave), ng = wave - ks * NG;
   const int k_begin = active ? ks * chunk : 0;
   const int k_end = active ? ((k_begin + chunk < KK) ? k_begin + chunk : KK) : 0;
   // uniform base (scalar registers) + one 32-bit per-lane offset: the loads need no per-lane 64-bit math
@@ -162,20 +171,20 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
     if (colt) {
       int n = n0 + tid;
       bool ok = n < N;
-      if (ok && p.bias) c0 = gld(p.bias + n);
-      if (ok && hasgn) { c1 = gld(p.gamma + n); c2 = gld(p.beta + n); }
-      if (ok && p.bias2) c3 = gld(p.bias2 + n);
+      if (ok && CP(bias)) c0 = gld(CP(bias) + n);
+      if (ok && hasgn) { c1 = gld(CP(gamma) + n); c2 = gld(CP(beta) + n); }
+      if (ok && CP(bias2)) c3 = gld(CP(bias2) + n);
     }
     auto tb_load = [&](int e) -> float {
       int s = dTN.div(e), c = e - s * TN;
       int n = n0 + c;
       if (s >= nvs || n >= N) return 0.f;
       long long tt = t_uniform >= 0 ? t_uniform : gldll(tptr + b0 + s);
-      tt = tt < 0 ? 0 : (tt >= p.T ? p.T - 1 : tt);
-      return gld(p.tbias + (unsigned)tt * (unsigned)N + n);
+      tt = tt < 0 ? 0 : (tt >= CP(T) ? CP(T) - 1 : tt);
+      return gld(CP(tbias) + (unsigned)tt * (unsigned)N + n);
     };
     auto ps_load = [&](int i) -> float {
-      return (i < nvs * GN_GROUPS * 2) ? gld(p.pro_stats + (unsigned)b0 * GN_GROUPS * 2 + i) : 0.f;
+      return (i < nvs * GN_GROUPS * 2) ? gld(CP(pro_stats) + (unsigned)b0 * GN_GROUPS * 2 + i) : 0.f;
     };
     float tbv[2] = {0.f, 0.f}, psv = 0.f;
     if (hastb) {
@@ -187,14 +196,14 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
     // identity residual tile
     f32x4 rv[2];
     int ro[2] = {-1, -1};
-    const int nRes4 = G.nRes4;
+    const int nRes4 = CG(nRes4);
     auto res_item = [&](int e, int* o) -> f32x4 {
-      int row = dTN4.div(e), c4 = e - row * G.tn4;
+      int row = dTN4.div(e), c4 = e - row * CG(tn4);
       *o = row * TNp + 4 * c4;
       int left = N - n0 - 4 * c4;
       if (row >= nvs * Lout) left = 0;
-      const float* sp = p.res + ((unsigned)b0 * Lout + row) * (unsigned)p.ldres + n0 + 4 * c4;
-      return G.vecr ? load4<true>(sp, left) : load4<false>(sp, left);
+      const float* sp = CP(res) + ((unsigned)b0 * Lout + row) * (unsigned)CP(ldres) + n0 + 4 * c4;
+      return CG(vecr) ? load4<true>(sp, left) : load4<false>(sp, left);
     };
     if (hasres) {
 #pragma unroll
@@ -205,10 +214,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
     // prologue the source is dL/d(Mish output); it is multiplied by the saved mish'(z)*gamma on the way
     // in (the slab then holds dL/dxhat) and the saved xhat goes to yslab with the same indexing.
     {
-      const FastDiv dC4(G.c4n, G.mC4), dNv(nv, G.mNv);
-      const int c4n = G.c4n, total = G.nValid4, vlo = G.vlo;
-      const float* pg = p.pro_g;
-      const float* py = p.pro_y;
+      const FastDiv dC4(CG(c4n), CG(mC4)), dNv(nv, CG(mNv));
+      const int c4n = CG(c4n), total = CG(nValid4), vlo = CG(vlo);
+      const float* pg = CP(pro_g);
+      const float* py = CP(pro_y);
       for (int base = tid; base < total; base += 4 * nthr) {
         f32x4 v[4], m[4], y[4];
         int so[4], yo[4];
@@ -241,8 +250,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
             }
           }
       }
-      const FastDiv dHr(G.hr, G.mHr);
-      const int nh = G.nHalo4, hr = G.hr;
+      const FastDiv dHr(CG(hr), CG(mHr));
+      const int nh = CG(nHalo4), hr = CG(hr);
       for (int idx = tid; idx < nh; idx += nthr) {
         int h = dC4.div(idx), c4 = idx - h * c4n;
         int s = dHr.div(h), k = h - s * hr;
@@ -251,10 +260,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
       }
     }
     if (has2) {           // second source rows at the output positions -> slab2
-      const FastDiv dC4(G.c4n2, G.mC4b);
-      const int c4n = G.c4n2, total = G.nX24, C2 = p.Cin2;
-      const float* p2 = p.x2;
-      const unsigned ldx2 = p.ldx2;
+      const FastDiv dC4(CG(c4n2), CG(mC4b));
+      const int c4n = CG(c4n2), total = CG(nX24), C2 = CP(Cin2);
+      const float* p2 = CP(x2);
+      const unsigned ldx2 = CP(ldx2);
       for (int base = tid; base < total; base += 2 * nthr) {
         f32x4 v[2];
         int so[2] = {-1, -1};
@@ -313,11 +322,11 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
   //   dY = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat * xhat))
   if (haspro) {
     if (active) {
-      const int gch = p.pro_gch, cnt4 = G.pcnt4, pg4 = G.pgch4, ninst = S * GN_GROUPS;
-      const int ts = G.ts_pro;
+      const int gch = CP(pro_gch), cnt4 = CG(pcnt4), pg4 = CG(pgch4), ninst = S * GN_GROUPS;
+      const int ts = CG(ts_pro);
       const int team = ts == 64 ? (tid >> 6) : (tid >> 4), tl = tid & (ts - 1),
                 nteams = ts == 64 ? (nthr >> 6) : (nthr >> 4);
-      const FastDiv dG(pg4, G.mPGch4);
+      const FastDiv dG(pg4, CG(mPGch4));
       const float icnt = 1.f / (float)(cnt4 * 4);
       for (int inst = team; inst < ninst; inst += nteams) {
         int s = inst >> 3, gi = inst & 7;
@@ -365,7 +374,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
       acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-  const FastDiv dCb(cbpt, G.mCbpt);
+  const FastDiv dCb(cbpt, CG(mCbpt));
   for (int base = k_begin; base < k_end; base += WB) {
     if (base != k_begin) {                      // later blocks (large reductions only): reload the registers
       const float* wu = pw + (size_t)base * wstep;
@@ -417,7 +426,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
 
   // ---- split-K partials -> LDS.  C/D layout: col = lane&15, row = 4*(lane>>4) + reg -------
   float* red = smem;
-  float* red2 = smem + G.red1;
+  float* red2 = smem + CG(red1);
   const int kstride = TM * TNp;
   if (active) {
 #pragma unroll
@@ -435,10 +444,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
   STAMP(6);
   if (!active) return;
 
-  const FastDiv dOs(p.osplit > 0 ? p.osplit : 1, G.mOs);
-  const int osplit = p.osplit;
-  const unsigned ldo = p.ldo;
-  const bool veco = G.veco != 0;
+  const FastDiv dOs(CP(osplit) > 0 ? CP(osplit) : 1, CG(mOs));
+  const int osplit = CP(osplit);
+  const unsigned ldo = CP(ldo);
+  const bool veco = CG(veco) != 0;
   // finish 4 adjacent output columns: time bias, second-source sum, residual, store
   auto finish = [&](f32x4 v, int s, int row, int col) {
     const int o = row * TNp + col;
@@ -469,14 +478,14 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
 
   if (hasgn) {
     // ---- split-K reduce + bias, GroupNorm statistics (two passes), normalise, Mish: per team --------
-    const int gch = p.gch, g4 = G.gch4, cnt4 = G.cnt4, gpt = G.gpt, ninst = S * gpt;
-    const int ts = G.ts_epi;
+    const int gch = CP(gch), g4 = CG(gch4), cnt4 = CG(cnt4), gpt = CG(gpt), ninst = S * gpt;
+    const int ts = CG(ts_epi);
     const int team = ts == 64 ? (tid >> 6) : (tid >> 4), tl = tid & (ts - 1),
               nteams = ts == 64 ? (nthr >> 6) : (nthr >> 4);
-    const FastDiv dG(g4, G.mGch4), dGpt(gpt, G.mGpt);
+    const FastDiv dG(g4, CG(mGch4)), dGpt(gpt, CG(mGpt));
     const float icnt = 1.f / (float)(cnt4 * 4);
-    float* sy = p.save_y;
-    float* sg = p.save_g;
+    float* sy = CP(save_y);
+    float* sg = CP(save_g);
     for (int inst = team; inst < ninst; inst += nteams) {
       int s = dGpt.div(inst), gi = inst - s * gpt;
       if (s >= nvs) continue;
@@ -499,8 +508,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
         sq += hsum(d * d);
       }
       const float rstd = 1.f / sqrtf(team_sum(sq, ts) * icnt + GN_EPS);
-      if (tl == 0 && p.save_stats) {
-        float* o = p.save_stats + ((unsigned)(b0 + s) * GN_GROUPS + (n0 / gch + gi)) * 2;
+      if (tl == 0 && CP(save_stats)) {
+        float* o = CP(save_stats) + ((unsigned)(b0 + s) * GN_GROUPS + (n0 / gch + gi)) * 2;
         gst(o, mean);
         gst(o + 1, rstd);
       }
@@ -526,9 +535,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
       }
     }
   } else {
-    const int nitems = G.nRes4;            // TM * TN / 4
+    const int nitems = CG(nRes4);            // TM * TN / 4
     for (int e = tid; e < nitems; e += nthr) {
-      int row = dTN4.div(e), col = 4 * (e - row * G.tn4);
+      int row = dTN4.div(e), col = 4 * (e - row * CG(tn4));
       if (row >= nvs * Lout || n0 + col >= N) continue;
       int s = dLout.div(row);
       f32x4 v = *(const f32x4*)&colp[col];
@@ -542,8 +551,17 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const ConvGeo& G, floa
 template <int MI, int NI, bool VEC>
 __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const ConvP& p = L.p[blockIdx.z];
-  conv_body<MI, NI, VEC>(p, L.g, smem, blockIdx.x * L.g.S, blockIdx.y * L.g.TN, threadIdx.x, p.t_uniform, p.t);
+  typedef const __attribute__((address_space(4))) unsigned* kargp;
+  kargp ka = (kargp)__builtin_amdgcn_kernarg_segment_ptr();      // L is the only argument: offset 0
+  const int lane = threadIdx.x & 63, z = blockIdx.z;
+  DV dv;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = lane + 64 * k;
+    const int src = j < CPW ? z * CPW + j : CG0 / 4 + (j - CPW);
+    dv.v[k] = j < CVIEW_DW ? ka[src] : 0u;
+  }
+  conv_body<MI, NI, VEC>(dv, smem, blockIdx.x * CG(S), blockIdx.y * CG(TN), threadIdx.x, CP(t_uniform), CP(t));
 }
 
 template <int MI, int NI>

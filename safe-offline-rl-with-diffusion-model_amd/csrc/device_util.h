@@ -108,4 +108,26 @@ __device__ __forceinline__ f32x4 load4(const float* sp, int left) {
 }
 
 
+// A launch / stage descriptor spread over the lanes of 4 VGPRs (dword i in lane i & 63 of register i >> 6);
+// a field is then ONE v_readlane_b32 with a constant lane instead of a scalar load + wait at every place
+// the compiler decides to (re)read it.
+struct DV { unsigned v[4]; };
+template <int IDX>
+__device__ __forceinline__ unsigned dget(const DV& d) {
+  return (unsigned)__builtin_amdgcn_readlane((int)d.v[IDX >> 6], IDX & 63);
+}
+template <typename T, int IDX>
+__device__ __forceinline__ T dfield(const DV& d) {
+  if constexpr (sizeof(T) == 4) {
+    union { unsigned u; T t; } c;
+    c.u = dget<IDX>(d);
+    return c.t;
+  } else {
+    static_assert(sizeof(T) == 8, "descriptor fields are 4 or 8 bytes");
+    union { unsigned long long u; T t; } c;
+    c.u = (unsigned long long)dget<IDX>(d) | ((unsigned long long)dget<IDX + 1>(d) << 32);
+    return c.t;
+  }
+}
+
 }  // namespace trebi
