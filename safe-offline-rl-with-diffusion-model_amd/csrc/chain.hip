@@ -494,8 +494,57 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
 #undef TREBI_STEP
       }
     };
-    // blocks 0..2 were requested a stage ahead; a slot is refilled as soon as its block is done
-    for (int i = 0; i < nb; i += 3) {
+    // Steady state for long reductions: full blocks of source 1 in a branch-free body (so that the waits the
+    // compiler inserts are exact: a block only waits for ITS slot, the two younger requests stay in flight).
+    // A refill past the last full block is clamped (harmless reload) and redone properly after the loop.
+    const int nfull1 = KK1 >> SH;
+    auto full = [&](const f32x4 (&w)[WREG], int bi) {
+      const int kb = bi << SH;
+      const int tau = dCb.div(kb);
+      int cb = kb - tau * cbpt;
+      int aoff = offA + tau * ldA + cb * 16;
+      f32x4 a[WH];
+#pragma unroll
+      for (int u = 0; u < WH; ++u) {
+        a[u] = *(const f32x4*)&smem[aoff];
+        aoff += 16;
+        if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
+      }
+#pragma unroll
+      for (int u = 0; u < WH; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], w[u * NI + ni][j], acc[0][ni], 0, 0, 0);
+    };
+    auto wfull = [&](f32x4 (&w)[WREG], int bi) {
+      bi = bi < nfull1 ? bi : nfull1 - 1;
+      const float* wu = pw + (size_t)(bi << SH) * wstep + wlane;
+#pragma unroll
+      for (int u = 0; u < WH; ++u) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) w[u * NI + ni] = gld4(wu + ni * 64);
+        wu += wstep;
+      }
+    };
+    int i = 0;
+    if (nfull1 >= 5) {
+      for (; i + 3 <= nfull1; i += 3) {
+        full(wreg[0], i);
+        wfull(wreg[0], i + 3);
+        full(wreg[1], i + 1);
+        wfull(wreg[1], i + 4);
+        full(wreg[2], i + 2);
+        wfull(wreg[2], i + 5);
+      }
+      // slots whose proper block is not a full block of source 1 were clamped: request the real ones
+      if (i + 0 >= nfull1 && i + 0 < nb) wblk<NI>(wreg[0], pw, wstep, wlane, blk_of(i + 0, SH, KK1, KK));
+      if (i + 1 >= nfull1 && i + 1 < nb) wblk<NI>(wreg[1], pw, wstep, wlane, blk_of(i + 1, SH, KK1, KK));
+      if (i + 2 >= nfull1 && i + 2 < nb) wblk<NI>(wreg[2], pw, wstep, wlane, blk_of(i + 2, SH, KK1, KK));
+    }
+    // remaining blocks (and short reductions entirely): blocks i..i+2 are in the slots
+    for (; i < nb; i += 3) {
       run(wreg[0], i);
       if (i + 3 < nb) wblk<NI>(wreg[0], pw, wstep, wlane, blk_of(i + 3, SH, KK1, KK));
       if (i + 1 < nb) {
