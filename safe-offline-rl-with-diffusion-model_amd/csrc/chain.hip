@@ -112,20 +112,19 @@ __device__ __forceinline__ Blk blk_of(int i, int sh, int KK1, int KK) {
   const int ke = i < nb1 ? KK1 : KK;
   int n = ke - kb;
   n = n < 0 ? 0 : (n > WH ? WH : n);
-  return Blk{kb, n};
+  return Blk{kb < KK ? kb : KK, n};                   // past the end: the slack steps behind the layer's weights
 }
-// weights of a block into the LAST n slots of w (the K loop enters its unrolled step sequence at slot WH-n)
+// Weights of a block into the first n slots of w.  Whole WH-step blocks are requested unconditionally (no
+// branches around the loads): the packed weights of every layer are followed by 8 steps of slack.
 template <int NI>
 __device__ __forceinline__ void wblk(f32x4 (&w)[WREG], const float* pw, unsigned wstep, unsigned wlane, Blk b) {
   constexpr int WH = WREG / NI;
   const float* wu = pw + (size_t)b.kb * wstep + wlane;
 #pragma unroll
   for (int u = 0; u < WH; ++u) {
-    if (u >= WH - b.n) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) w[u * NI + ni] = gld4(wu + ni * 64);
-      wu += wstep;
-    }
+    for (int ni = 0; ni < NI; ++ni) w[u * NI + ni] = gld4(wu + ni * 64);
+    wu += wstep;
   }
 }
 
@@ -445,54 +444,43 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
       const Blk bk = blk_of(i, SH, KK1, KK);
       const int kb = bk.kb, n = bk.n;
       f32x4 a[WH];
+#define TREBI_STEP(u, ACC)                                                                              \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)       \
+      ACC[0][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], w[(u) * NI + ni][j], ACC[0][ni], 0, 0, 0);
+#define TREBI_STEPS(ACC)                                                     \
+  switch (n) {                                                               \
+    case 8: if (WH > 7) { TREBI_STEP(7 % WH, ACC) } [[fallthrough]];         \
+    case 7: if (WH > 6) { TREBI_STEP(6 % WH, ACC) } [[fallthrough]];         \
+    case 6: if (WH > 5) { TREBI_STEP(5 % WH, ACC) } [[fallthrough]];         \
+    case 5: if (WH > 4) { TREBI_STEP(4 % WH, ACC) } [[fallthrough]];         \
+    case 4: if (WH > 3) { TREBI_STEP(3 % WH, ACC) } [[fallthrough]];         \
+    case 3: if (WH > 2) { TREBI_STEP(2 % WH, ACC) } [[fallthrough]];         \
+    case 2: if (WH > 1) { TREBI_STEP(1 % WH, ACC) } [[fallthrough]];         \
+    case 1: { TREBI_STEP(0, ACC) } [[fallthrough]];                          \
+    default: break;                                                          \
+  }
       if (i < nb1) {
         int tau = dCb.div(kb);
         int cb = kb - tau * cbpt;
         int aoff = offA + tau * ldA + cb * 16;
 #pragma unroll
         for (int u = 0; u < WH; ++u) {
-          if (u >= WH - n) {
-            a[u] = *(const f32x4*)&smem[aoff];
-            aoff += 16;
-            if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
-          }
+          a[u] = *(const f32x4*)&smem[u < n ? aoff : offA];       // unused slots: any valid address
+          aoff += 16;
+          if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
         }
-#define TREBI_STEP(u, ACC)                                                                              \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)       \
-      ACC[0][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], w[(u) * NI + ni][j], ACC[0][ni], 0, 0, 0);
-        switch (WH - n) {
-          case 0: if (WH > 0) { TREBI_STEP(0, acc) } [[fallthrough]];
-          case 1: if (WH > 1) { TREBI_STEP(1, acc) } [[fallthrough]];
-          case 2: if (WH > 2) { TREBI_STEP(2, acc) } [[fallthrough]];
-          case 3: if (WH > 3) { TREBI_STEP(3, acc) } [[fallthrough]];
-          case 4: if (WH > 4) { TREBI_STEP(4 % WH, acc) } [[fallthrough]];
-          case 5: if (WH > 5) { TREBI_STEP(5 % WH, acc) } [[fallthrough]];
-          case 6: if (WH > 6) { TREBI_STEP(6 % WH, acc) } [[fallthrough]];
-          case 7: if (WH > 7) { TREBI_STEP(7 % WH, acc) } [[fallthrough]];
-          default: break;
-        }
+        TREBI_STEPS(acc)
       } else {
         int aoff = off2 + (kb - KK1) * 16;
 #pragma unroll
         for (int u = 0; u < WH; ++u) {
-          if (u >= WH - n) {
-            a[u] = *(const f32x4*)&smem[aoff];
-            aoff += 16;
-          }
+          a[u] = *(const f32x4*)&smem[u < n ? aoff : off2];
+          aoff += 16;
         }
-        switch (WH - n) {
-          case 0: if (WH > 0) { TREBI_STEP(0, acc2) } [[fallthrough]];
-          case 1: if (WH > 1) { TREBI_STEP(1, acc2) } [[fallthrough]];
-          case 2: if (WH > 2) { TREBI_STEP(2, acc2) } [[fallthrough]];
-          case 3: if (WH > 3) { TREBI_STEP(3, acc2) } [[fallthrough]];
-          case 4: if (WH > 4) { TREBI_STEP(4 % WH, acc2) } [[fallthrough]];
-          case 5: if (WH > 5) { TREBI_STEP(5 % WH, acc2) } [[fallthrough]];
-          case 6: if (WH > 6) { TREBI_STEP(6 % WH, acc2) } [[fallthrough]];
-          case 7: if (WH > 7) { TREBI_STEP(7 % WH, acc2) } [[fallthrough]];
-          default: break;
-        }
-#undef TREBI_STEP
+        TREBI_STEPS(acc2)
       }
+#undef TREBI_STEPS
+#undef TREBI_STEP
     };
     // Steady state for long reductions: full blocks of source 1 in a branch-free body (so that the waits the
     // compiler inserts are exact: a block only waits for ITS slot, the two younger requests stay in flight).

@@ -366,7 +366,8 @@ struct Builder {
                     int Cin2) {
     int Cin_p = rup(Cin, 16), Cin2_p = W2 ? rup(Cin2, 16) : 0, Npad = rup(N, 16);
     int KK = (ntaps * Cin_p + Cin2_p) / 16;
-    std::vector<float> P((size_t)KK * 16 * Npad, 0.f);
+    // + 8 zero steps of slack: the chain kernels request whole 8-step blocks without bounds checks
+    std::vector<float> P((size_t)(KK + 8) * 16 * Npad, 0.f);
     auto put = [&](int kk, int cc, int n, float v) {   // cc in [0,16)
       int g = cc >> 2, j = cc & 3;
       P[(((size_t)kk * 4 + g) * Npad + n) * 4 + j] = v;
@@ -1723,8 +1724,14 @@ static int ensure_plans(trebi_sampler* s, float* x, float* values, float* costs)
   const int B = s->B, D = d.step.transition_dim;
   const char* e_chain = getenv("TREBI_CHAIN");
   const char* e_maxn = getenv("TREBI_CHAIN_MAXN");
-  const int chain_S = (e_chain && atoi(e_chain) == 0) || B > 1024 ? 0 : 1;
-  const int chain_max_n = e_maxn ? atoi(e_maxn) : 64;   // measured best at 64 candidates (wider layers want more workgroups)
+  // Chains pay off while a launch is latency-bound; one workgroup per S candidates cannot fill the chip at
+  // larger batches.  Measured (ms per planning call, chains vs none): 64 candidates 21.6 / 25.9, 128: 24.2 / 26.9,
+  // 256: 29.7 (S=2) / 33.2, 512: 45.9 (S=2) / 48.0; wider layers (N > 64) and larger S lose.
+  const char* e_maxb = getenv("TREBI_CHAIN_MAXB");
+  const char* e_cs = getenv("TREBI_CHAIN_S");
+  const int chain_max_b = e_maxb ? atoi(e_maxb) : 512;
+  const int chain_S = (e_chain && atoi(e_chain) == 0) || B > chain_max_b ? 0 : (e_cs ? atoi(e_cs) : (B <= 160 ? 1 : 2));
+  const int chain_max_n = e_maxn ? atoi(e_maxn) : 64;
   std::vector<RStage> tab;
   s->vf_grad.clear(); s->vf_nograd.clear(); s->unet_plan.clear();
   Binding bu;
