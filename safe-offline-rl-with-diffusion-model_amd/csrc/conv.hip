@@ -561,7 +561,10 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L) {
     const int src = j < CPW ? z * CPW + j : CG0 / 4 + (j - CPW);
     dv.v[k] = j < CVIEW_DW ? ka[src] : 0u;
   }
-  conv_body<MI, NI, VEC>(dv, smem, blockIdx.x * CG(S), blockIdx.y * CG(TN), threadIdx.x, CP(t_uniform), CP(t));
+  // blockIdx.x = column tile, blockIdx.y = candidate group: workgroups are dealt to the 8 XCDs round-robin by
+  // linear id, so the workgroups that share a weight slice land on the same XCD (one L2 fetches the slice
+  // instead of all eight; the activations are tiny)
+  conv_body<MI, NI, VEC>(dv, smem, blockIdx.y * CG(S), blockIdx.x * CG(TN), threadIdx.x, CP(t_uniform), CP(t));
 }
 
 template <int MI, int NI>
@@ -570,7 +573,7 @@ static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hip
   ConvLaunch LL = L;
   LL.g = conv_make_geo(p, tl);
   size_t lds = (size_t)LL.g.total * sizeof(float);
-  dim3 grid((p.B + tl.S - 1) / tl.S, p.Npad / (16 * tl.NI * tl.NG), nz);
+  dim3 grid(p.Npad / (16 * tl.NI * tl.NG), (p.B + tl.S - 1) / tl.S, nz);
   dim3 block(64 * tl.NG * tl.KS);
   bool vec = conv_vec_ok(L.p[0]) && (nz < 2 || conv_vec_ok(L.p[1]));
   if (vec)
