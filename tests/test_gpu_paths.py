@@ -1,0 +1,32 @@
+"""Every launch strategy of the library produces the reference's chains.
+
+The planner picks between single-layer launches (split-K conv kernel), resident chains (direct and
+split-K stages, one or two candidates per workgroup) and single-layer direct launches by batch size;
+diagnostic environment switches force each of them.  The switches are read once per process, so each
+configuration runs the golden-loop check (`test_fused_loop_golden`, tolerance 5e-4 as stated there) in ONE
+child process, sequentially."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CONFIGS = {
+    'no_chains': {'TREBI_CHAIN': '0'},
+    'split_k_chains_only': {'TREBI_CHAIN_DIRECT': '0'},
+    'wide_chains_two_per_workgroup': {'TREBI_CHAIN_MAXN': '256', 'TREBI_CHAIN_S': '2'},
+    'direct_single_layers': {'TREBI_DIRECT_SINGLE': '1', 'TREBI_CHAIN': '0'},
+}
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_golden_loops_under_path(name):
+    env = dict(os.environ, **CONFIGS[name])
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_gpu_sampling.py'), '-q', '-x', '-m', 'gpu',
+           '-k', 'fused_loop_golden', '-p', 'no:cacheprovider', '--timeout', '120', '--timeout-method', 'thread']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
