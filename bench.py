@@ -167,6 +167,14 @@ def main():
         F_vf = guide._net().flops() + guide._net().flops(backward=True)
         ngs, ts = PLAN_KW['n_guide_steps'], PLAN_KW['t_stopgrad']
         gflop_nominal = T * (F_unet + 2 * ngs * F_vf) / 1e9              # SURVEY.md 8d formula
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # figure is the committed rocprofv3 --pmc measurement of this same command (profiles/, tools/analyze_traffic.py)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_d_hbm_traffic.json')) as f:
+                traffic = json.load(f)['conv_gemm_kernel']['hbm_bytes_per_launch']
+        except Exception:
+            pass
         avg_us = prof['gemm_us'] / max(prof['gemm_launches'], 1)
         flops_per_launch = prof['gemm_flops'] / max(prof['gemm_launches'], 1)
         achieved = flops_per_launch / (avg_us * 1e-6) / 1e12
@@ -184,9 +192,10 @@ def main():
                        'candidates_per_gpu': B, 'global_candidates': n_global,
                        'parallelism': f'candidate-sharded x{world}', 'skip_dead_evals': bool(args.skip_dead_evals),
                        'algorithmic_gflop_per_trajectory': gflop_nominal},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_kernel (implicit-GEMM Conv1d, f32 MFMA)',
+            'roofline': {'bound': 'mfma',
+                         'kernel': 'implicit-GEMM Conv1d on f32 MFMA (conv_gemm_kernel + resident_chain_kernel)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'avg_launch_us': avg_us, 'launches_per_step': prof['gemm_launches'],
                          'algorithmic_flops_per_launch': flops_per_launch,
                          'eager_loop_ms': prof['loop_us'] / 1e3},
