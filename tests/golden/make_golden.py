@@ -106,6 +106,10 @@ CONFIGS = {
     'walker148': dict(obs=17, act=6, unet_mults=(1, 4, 8), B=3,
                       kw=dict(scale=0.1, t_stopgrad=2, n_guide_steps=1, cost_grad_weight=5.0, guide_type=0,
                               state_grad_mask=True)),
+    # the reference's in-repo halfcheetah shape (config/locomotion.py:295-314): horizon 4, dim_mults (1,4,8) for
+    # all three nets; the TemporalUnet then skips its last Upsample1d (temporal.py:95,109), SURVEY.md 8f rank 4
+    'halfcheetah_h4': dict(obs=17, act=6, unet_mults=(1, 4, 8), value_mults=(1, 4, 8), H=4, B=4,
+                           kw=dict(scale=0.001, t_stopgrad=4, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0)),
 }
 H, T, DIM = 32, 20, 32
 VMULTS = (1, 2, 4, 8)
@@ -127,7 +131,16 @@ def main():
                                     'posterior_mean_coef2')}
     np.savez_compressed(os.path.join(HERE, 'schedule_T20.npz'), **sched)
 
+    only = sys.argv[1:]                                       # optional: generate only the named configs
     for name, cfg in CONFIGS.items():
+        if only and name not in only:
+            continue
+        write_config(name, cfg, temporal, diffusion, guides, functions, helpers)
+
+
+def write_config(name, cfg, temporal, diffusion, guides, functions, helpers):
+    if True:
+        H, VMULTS = cfg.get('H', globals()['H']), cfg.get('value_mults', globals()['VMULTS'])
         obs, act, B = cfg['obs'], cfg['act'], cfg['B']
         D = obs + act
         out = dict(obs=obs, act=act, B=B, H=H, T=T, dim=DIM, unet_mults=np.array(cfg['unet_mults']),
