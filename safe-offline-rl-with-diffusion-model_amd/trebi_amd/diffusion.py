@@ -283,8 +283,11 @@ class GaussianDiffusion(nn.Module):
         rb('posterior_log_variance_clipped', torch.log(torch.clamp(posterior_variance, min=1e-20)))
         # np.sqrt on a torch tensor (as the reference does, diffusion.py:113-116) is not bit-identical to
         # torch.sqrt for every entry; the tables must be, so the same mixed expression is kept
-        rb('posterior_mean_coef1', betas * np.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
-        rb('posterior_mean_coef2', (1. - alphas_cumprod_prev) * np.sqrt(alphas) / (1. - alphas_cumprod))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', DeprecationWarning)       # numpy 2 on Tensor.__array_wrap__
+            rb('posterior_mean_coef1', betas * np.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+            rb('posterior_mean_coef2', (1. - alphas_cumprod_prev) * np.sqrt(alphas) / (1. - alphas_cumprod))
         self.loss_fn = _LossWeights(self.get_loss_weights(action_weight, loss_discount, loss_weights))
         self._samplers = {}
         self._buffers_for = {}

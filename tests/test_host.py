@@ -64,3 +64,20 @@ def test_shard_bounds_partition():
             assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_policy_host_pieces():
+    """GuidedPolicy's dataset-free pieces: the normaliser arithmetic (normalization.py:145-149) and the refusal
+    of preprocess names (the reference evals them inside its datasets package)."""
+    from diffuser.sampling import GuidedPolicy, Trajectories
+    from trebi_amd.policy import GaussianNormalizer, _compose
+    n = GaussianNormalizer({'observations': ([1.0, 2.0], [2.0, 4.0])})
+    x = np.array([[3.0, 10.0]], np.float32)
+    np.testing.assert_allclose(n.normalize(x, 'observations'), [[1.0, 2.0]])
+    np.testing.assert_allclose(n.unnormalize(n.normalize(x, 'observations'), 'observations'), x)
+    assert _compose([lambda v: v + 1, lambda v: v * 2])(1) == 4
+    with pytest.raises(RuntimeError, match='callables'):
+        _compose(['arctanh_actions'])
+    assert Trajectories._fields == ('actions', 'observations', 'rewards', 'terminals', 'values', 'costs')
+    assert GuidedPolicy.__call__.__code__.co_varnames[:6] == ('self', 'conditions', 'batch_size', 'verbose',
+                                                              'cost_threshold', 'plan_horizon')
