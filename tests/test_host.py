@@ -81,3 +81,25 @@ def test_policy_host_pieces():
     assert Trajectories._fields == ('actions', 'observations', 'rewards', 'terminals', 'values', 'costs')
     assert GuidedPolicy.__call__.__code__.co_varnames[:6] == ('self', 'conditions', 'batch_size', 'verbose',
                                                               'cost_threshold', 'plan_horizon')
+
+
+def test_reference_checkpoint_format_loads(tmp_path):
+    """A file in the Trainer's format (training.py:140-150: {'step','model','ema'} of state_dicts with the
+    reference's names) loads with strict=True; a foreign file is refused."""
+    from diffuser.models import TemporalUnet, GaussianDiffusion
+    from trebi_amd import checkpoint
+    mk = lambda: GaussianDiffusion(TemporalUnet(32, 23, 0), 32, 17, 6, n_timesteps=20, loss_type='l2',
+                                   clip_denoised=False, predict_epsilon=False)
+    src, dst = mk(), mk()
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(0.5)
+    path = os.path.join(tmp_path, 'state_7.pt')
+    torch.save({'step': 7, 'model': src.state_dict(), 'ema': src.state_dict()}, path)
+    assert checkpoint.load_into(dst, path) == 7
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    bad = os.path.join(tmp_path, 'other.pt')
+    torch.save({'weights': 1}, bad)
+    with pytest.raises(RuntimeError, match='not a reference trainer checkpoint'):
+        checkpoint.load_into(dst, bad)
