@@ -953,10 +953,12 @@ struct GemmProfile {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   std::vector<double> flops;
   std::vector<std::string> names;  // layer + tile of each timed launch (TREBI_PROFILE_DUMP diagnostics)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> null_ev;   // empty brackets: the cost of the bracketing itself
   size_t used = 0;
   void reset() { used = 0; flops.clear(); names.clear(); }
   ~GemmProfile() {
     for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : null_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
 };
 
@@ -1830,6 +1832,17 @@ extern "C" int trebi_sampler_run(trebi_sampler* s, const float* noise, const flo
     HIPCHK(hipEventRecord(s->ev_a, st));
     if (int e = enqueue_loop(s, noise, cond, thr, x, values, costs, chain, st, &s->prof)) return e;
     HIPCHK(hipEventRecord(s->ev_b, st));
+    if (s->prof.null_ev.empty())
+      for (int i = 0; i < 16; ++i) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        s->prof.null_ev.push_back({a, b});
+      }
+    for (auto& e : s->prof.null_ev) {          // empty brackets, subtracted from every launch bracket
+      HIPCHK(hipEventRecord(e.first, st));
+      HIPCHK(hipEventRecord(e.second, st));
+    }
     s->have_loop_time = true;
     return 0;
   }
@@ -1868,11 +1881,22 @@ extern "C" int trebi_sampler_get_profile(trebi_sampler* s, double* gemm_us_total
   if (!s) return fail(TREBI_BAD_ARG, "null sampler");
   if (!s->have_loop_time) return fail(TREBI_BAD_ARG, "no profiled run recorded");
   HIPCHK(hipEventSynchronize(s->ev_b));
-  double us = 0, fl = 0;
+  double us = 0, fl = 0, null_us = 0;
+  {
+    std::vector<double> nu;
+    for (auto& e : s->prof.null_ev) {
+      HIPCHK(hipEventSynchronize(e.second));
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+      nu.push_back(1e3 * ms);
+    }
+    std::sort(nu.begin(), nu.end());
+    if (!nu.empty()) null_us = nu[nu.size() / 2];
+  }
   for (size_t i = 0; i < s->prof.used; ++i) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, s->prof.ev[i].first, s->prof.ev[i].second));
-    us += 1e3 * ms;
+    us += std::max(0.0, 1e3 * ms - null_us);
     fl += s->prof.flops[i];
   }
   if (const char* path = getenv("TREBI_PROFILE_DUMP")) {   // diagnostics: per-layer totals of the profiled run
