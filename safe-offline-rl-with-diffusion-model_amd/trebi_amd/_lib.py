@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtrebi_hip.so')
+LIB_PATH = os.environ.get('TREBI_LIB') or os.path.join(_HERE, 'libtrebi_hip.so')   # TREBI_LIB: A/B builds on one box (diagnostics)
 
 c_float_p = C.POINTER(C.c_float)
 c_i64_p = C.POINTER(C.c_int64)
