@@ -104,6 +104,8 @@ def _cond_tensors(cond, keys, B, obs, device):
 def feasibility_rule(r_y, cost_y, cost_threshold):
     """functions.py:126-129 on the library (global over the batch)."""
     n = r_y.numel()
+    if n == 0:
+        return r_y.clone()
     thr = torch.as_tensor(cost_threshold, device=r_y.device, dtype=torch.float32).expand(n).contiguous()
     out = torch.empty_like(r_y)
     _lib.check(_lib.lib().trebi_feasibility_rule(_ctx(r_y.device), _lib.ptr(r_y.contiguous()),
@@ -114,6 +116,8 @@ def feasibility_rule(r_y, cost_y, cost_threshold):
 
 def argsort_descending(values):
     order = torch.empty(values.numel(), device=values.device, dtype=torch.int64)
+    if values.numel() == 0:
+        return order
     _lib.check(_lib.lib().trebi_argsort_desc(_ctx(values.device), _lib.ptr(values.contiguous()), values.numel(),
                                              _lib.ptr(order), _stream(values.device)))
     return order
@@ -393,6 +397,10 @@ class GaussianDiffusion(nn.Module):
         chain|None) for this rank's candidates.  ShardedPlanner all-gathers values/costs."""
         device = self.betas.device
         B, H, D = shape
+        if B == 0:                                  # empty batch: nothing to plan (torch would return empty tensors)
+            e = torch.empty(0, device=device)
+            chain = torch.empty(self.n_timesteps + 1, 0, H, D, device=device) if return_chain else None
+            return torch.empty(0, H, D, device=device), e, e.clone(), chain
         kind = _FUSED_KINDS[sample_fn]
         keys = sorted(cond.keys())
         s = self._sampler(kind, B, H, keys, sample_kwargs, device, use_graph, skip_dead_evals)

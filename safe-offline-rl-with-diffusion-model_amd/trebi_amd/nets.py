@@ -114,6 +114,13 @@ class _HipNet(nn.Module):
         except Exception:
             pass
 
+    def _check_x(self, x):
+        """[batch, horizon, >= transition_dim] (wider rows are read as their first transition_dim columns, which is
+        how ValueGuide's x[:, :, :transition_dim] slice arrives without a copy); anything else is refused."""
+        if x.dim() != 3 or x.shape[1] != self.horizon or x.shape[2] < self.transition_dim:
+            raise RuntimeError(f'expected x of shape [batch, {self.horizon}, {self.transition_dim}], got {tuple(x.shape)}')
+        return x.shape
+
     def _workspace(self, B, device, query):
         key = (B, str(device))
         if key not in self._ws:
@@ -161,8 +168,9 @@ class TemporalUnet(_HipNet):
     @torch.no_grad()
     def forward(self, x, cond, time):
         """x: [batch, horizon, transition] -> same shape (temporal.py:120-151)."""
-        B, H, D = x.shape
-        assert H == self.horizon and D >= self.transition_dim, (x.shape, self.horizon, self.transition_dim)
+        B, H, D = self._check_x(x)
+        if B == 0:                                   # empty batch: what torch's Conv1d stack returns
+            return torch.empty(0, H, self.transition_dim, device=x.device, dtype=torch.float32)
         x, ldx = self._rows(x)
         t = self._time(time, B, x.device)
         h = self.net_handle(x.device)
@@ -185,8 +193,10 @@ class ValueFunction(_HipNet):
                     transition_dim, dim, dim_mults)
 
     def _run(self, x, time, want_grad):
-        B, H, D = x.shape
-        assert H == self.horizon and D >= self.transition_dim, (x.shape, self.horizon, self.transition_dim)
+        B, H, D = self._check_x(x)
+        if B == 0:
+            return (torch.empty(0, device=x.device, dtype=torch.float32),
+                    torch.empty(0, H, D, device=x.device, dtype=torch.float32) if want_grad else None)
         x, ldx = self._rows(x)
         t = self._time(time, B, x.device)
         h = self.net_handle(x.device)
