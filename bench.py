@@ -92,10 +92,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='candidates per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--guide-steps', type=int, default=PLAN_KW['n_guide_steps'],
+                    help='n_guide_steps (headline 2; SURVEY 8d also asks for 1)')
     ap.add_argument('--skip-dead-evals', action='store_true',
                     help='also drop guide evaluations whose result cannot reach an output (not the default)')
     args = ap.parse_args()
 
+    PLAN_KW['n_guide_steps'] = args.guide_steps
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -187,7 +190,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic (seeded random weights, N(0,1) noise and observation)',
             'config': {'workload': 'halfcheetah-medium-expert-v2 shapes (obs 17 + act 6), H=32, T=20, '
-                                   f'{B} candidates per GPU, reward+cost guide, n_guide_steps=2, '
+                                   f'{B} candidates per GPU, reward+cost guide, n_guide_steps={args.guide_steps}, '
                                    'TemporalUnet/ValueFunction dim_mults (1,2,4,8)',
                        'candidates_per_gpu': B, 'global_candidates': n_global,
                        'parallelism': f'candidate-sharded x{world}', 'skip_dead_evals': bool(args.skip_dead_evals),
