@@ -3,18 +3,28 @@
 // At planning batch sizes a layer's matrix work takes ~1 us while a kernel that reads its input from
 // global memory, stages it, runs, and stores the result takes 7-9 us of mostly latency.  A workgroup that
 // owns S whole candidates and ALL output columns of a layer depends only on its own earlier outputs, so a
-// run of such layers executes here as stages of one kernel:
+// run of such layers executes here as stages of one kernel (rc_stage):
 //   * a stage's output is written straight into the LDS layout its consumers read (canonical layout, see
 //     RStage in common.h) -- no global round trip, no store drain between layers; tensors that something
 //     outside the chain needs (skip connections, saved GroupNorm operands, the chain's result) are also
 //     stored to global memory, fire and forget;
-//   * the packed weights of the NEXT stage's first reduction block are requested before this stage's
-//     epilogue, and within a stage the weight stream is double-buffered in registers;
+//   * stage descriptors are held in VGPRs (DV, device_util.h), loaded with vector loads a stage ahead;
+//   * packed weights sit in three 8-step register slots; the first three blocks of the NEXT stage (a whole
+//     narrow layer) are requested before this stage's epilogue, long reductions refill a slot as soon as
+//     its block is done (branch-free steady state, so the compiler's vmcnt waits are exact);
 //   * stages are separated by an LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier); outstanding global
 //     stores are drained only in front of a stage that reads a global tensor written earlier in the chain.
-// The arithmetic is the same as conv_body (conv.hip): v_mfma_f32_16x16x4_f32 implicit GEMM, split-K through
-// LDS, GroupNorm(8) + Mish (+ time bias, residual) per (candidate, group) team, GroupNorm backward as a
-// prologue of the backward layers -- here with the team's operands held in registers between the passes.
+// Two stage forms share the residency code, each with its own kernel instantiation (one kernel per form
+// keeps the register footprint within two waves per SIMD without spilling):
+//   DIRECT  a wave owns one 16-row x 16-column MFMA tile over the whole reduction, so the tile is final in
+//           registers: GroupNorm statistics by DPP + ds_bpermute (Chan-combined with ONE partner wave
+//           through LDS when a candidate spans two row tiles or a group two column tiles), Mish, time bias,
+//           residual and stores straight from the accumulators.  Also launched as a single stage with a
+//           column-tile grid (blockIdx.y) for wide layers (TREBI_DIRECT_SINGLE, diagnostic).
+//   split-K the form of conv_body (conv.hip): K split across waves, partials through LDS, per (candidate,
+//           group) teams -- here with the team's values held in registers between the passes.
+// The arithmetic is that of conv_body: v_mfma_f32_16x16x4_f32 implicit GEMM, GroupNorm(8) + Mish (+ time
+// bias, residual), GroupNorm backward as a prologue of the backward layers.
 #include "device_util.h"
 
 namespace trebi {
@@ -35,7 +45,7 @@ extern "C" int trebi_debug_read_cstamps(unsigned long long* out) {
 
 namespace {
 
-constexpr int WREG = 8;            // float4 weight registers per half of the double buffer
+constexpr int WREG = 8;            // float4 weight registers per slot (8 reduction steps of one 16-column tile)
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void drain_barrier() {
@@ -167,7 +177,7 @@ template <int MI, int NI, bool DIRECT>
 __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool has_next, float* smem, const int tid,
                                          const int b0, int t_uniform, const long long* tptr,
                                          f32x4 (&wreg)[3][WREG], int skey, int sidx) {
-  constexpr int WH = WREG / NI;    // reduction steps per register half
+  constexpr int WH = WREG / NI;    // reduction steps per register slot
   CSTAMP(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
