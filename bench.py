@@ -108,11 +108,21 @@ def main():
                      '(one process per GPU)')
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X: there is no CPU path')
+    # rehearsal on a one-GPU box: TREBI_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
+    # ranks on one device); the driver's runs use one GPU per rank over RCCL
+    rehearse = os.environ.get('TREBI_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(75, exit=True)      # a rehearsal that hangs says where
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=device)
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
 
     from diffuser.sampling import n_step_guided_and_constrained_p_sample as fn
     from trebi_amd.parallel import ShardedPlanner

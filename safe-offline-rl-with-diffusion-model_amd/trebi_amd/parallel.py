@@ -8,6 +8,7 @@ latency-bound (<= 64 KiB at 8192 candidates per GPU) -- after which every rank a
 and the sort to the global arrays; the owner of the winning candidate broadcasts its [H, D]
 trajectory.  One process per GPU; backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
 """
+import os
 from collections import namedtuple
 
 import torch
@@ -83,6 +84,11 @@ class ShardedPlanner:
             pad = torch.zeros(2 * m, dtype=packed.dtype, device=packed.device)
             pad[:B] = v_raw.reshape(-1)
             pad[m:m + B] = c.reshape(-1)
+            if pad.is_cuda and os.environ.get('TREBI_PLAN_SYNC', '1') == '1':
+                # the scores are needed on the host right after the exchange anyway; draining the launch stream first
+                # keeps the backend's side stream from queueing behind the captured loop (two ranks sharing one GPU
+                # over gloo stalled there; see tools/rehearse_ranks.py)
+                torch.cuda.current_stream(pad.device).synchronize()
             outs = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(outs, pad, group=self.group)          # single fused all-gather (values | costs)
             v_all = torch.cat([o[:n] for o, n in zip(outs, sizes)])
