@@ -6,7 +6,7 @@ import numpy as np
 from trebi_amd import spec, synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CONFIG_NAMES = ('pendulum', 'halfcheetah', 'hopper', 'walker148', 'halfcheetah_h4')
+CONFIG_NAMES = ('pendulum', 'halfcheetah', 'hopper', 'walker148', 'halfcheetah_h4', 'pendulum_h128')
 
 
 def load_fixture(name):

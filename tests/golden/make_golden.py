@@ -110,6 +110,11 @@ CONFIGS = {
     # all three nets; the TemporalUnet then skips its last Upsample1d (temporal.py:95,109), SURVEY.md 8f rank 4
     'halfcheetah_h4': dict(obs=17, act=6, unet_mults=(1, 4, 8), value_mults=(1, 4, 8), H=4, B=4,
                            kw=dict(scale=0.001, t_stopgrad=4, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0)),
+    # long-horizon toy run (test_cost_toyenv.sh:5 plans with horizon 128), SURVEY.md 8f rank 4.  The reference's
+    # ValueFunction only runs when its head sees one position (temporal.py:191 halves the horizon one time fewer
+    # than forward :225-228 downsamples), i.e. horizon <= 2^(len(dim_mults)+1): six levels for horizon 128
+    'pendulum_h128': dict(obs=3, act=1, unet_mults=(1, 2, 4, 8), value_mults=(1, 2, 4, 8, 8, 8), H=128, B=2,
+                          kw=dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=20.0, guide_type=0)),
 }
 H, T, DIM = 32, 20, 32
 VMULTS = (1, 2, 4, 8)
