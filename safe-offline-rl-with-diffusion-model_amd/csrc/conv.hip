@@ -151,7 +151,27 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
   const unsigned wlane = (unsigned)((g * Npad + n0 + ng * NI * 16 + lr) * 4);
   const unsigned wstep = (unsigned)Npad * 16u;     // floats per kk step
   f32x4 wreg[WB][NI];
-  {
+  // A reduction longer than one register block (large batches: no split-K) is software-pipelined in half
+  // blocks: while one half's MFMAs run, the other half's registers are refilled for the next block.  Those
+  // loads are unconditional -- steps past the layer re-read its last step -- so that the compiler's vmcnt
+  // waits are exact counts instead of vmcnt(0).
+  constexpr int HB = WB / 2;
+  const bool multi = k_end - k_begin > WB;
+  const int k_last = KK - 1;
+  auto wload = [&](int u0, int kbase) {
+#pragma unroll
+    for (int u = 0; u < HB; ++u) {
+      int k = kbase + u;
+      k = k < k_last ? k : k_last;
+      const float* wu = pw + (unsigned)k * wstep;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wreg[u0 + u][ni] = gld4(wu + wlane + ni * 64);
+    }
+  };
+  if (multi) {
+    wload(0, k_begin);
+    wload(HB, k_begin + HB);
+  } else {
     const float* wu = pw + (size_t)k_begin * wstep;
 #pragma unroll
     for (int u = 0; u < WB; ++u) {
@@ -375,51 +395,51 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
       acc2[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   const FastDiv dCb(cbpt, CG(mCbpt));
-  for (int base = k_begin; base < k_end; base += WB) {
-    if (base != k_begin) {                      // later blocks (large reductions only): reload the registers
-      const float* wu = pw + (size_t)base * wstep;
+  auto kstep = [&](int u, int kk, int& cb, int& aoff) {
+    if (kk < k_end) {
+      f32x4 a[MI];
+      if (kk < KK1) {
 #pragma unroll
-      for (int u = 0; u < WB; ++u) {
-        if (base + u < k_end) {
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) wreg[u][ni] = gld4(wu + wlane + ni * 64);
-        }
-        wu += wstep;
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc[mi][ni], 0, 0, 0);
+        aoff += 16;
+        if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
+      } else {
+        const int a2 = (kk - KK1) * 16;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab2[row2[mi] + a2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc2[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc2[mi][ni], 0, 0, 0);
       }
     }
-    int tau = dCb.div(base), cb = base - tau * cbpt;
+  };
+  if (multi) {
+    for (int base = k_begin; base < k_end; base += WB) {
+      int tau = dCb.div(base), cb = base - tau * cbpt;
+      int aoff = tau * ldA + cb * 16;
+#pragma unroll
+      for (int u = 0; u < HB; ++u) kstep(u, base + u, cb, aoff);
+      wload(0, base + WB);
+#pragma unroll
+      for (int u = HB; u < WB; ++u) kstep(u, base + u, cb, aoff);
+      wload(HB, base + WB + HB);
+    }
+  } else {
+    int tau = dCb.div(k_begin), cb = k_begin - tau * cbpt;
     int aoff = tau * ldA + cb * 16;
 #pragma unroll
-    for (int u = 0; u < WB; ++u) {
-      const int kk = base + u;
-      if (kk < k_end) {
-        f32x4 a[MI];
-        if (kk < KK1) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc[mi][ni], 0, 0, 0);
-          aoff += 16;
-          if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
-        } else {
-          const int a2 = (kk - KK1) * 16;
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab2[row2[mi] + a2];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni)
-                acc2[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc2[mi][ni], 0, 0, 0);
-        }
-      }
-    }
+    for (int u = 0; u < WB; ++u) kstep(u, k_begin + u, cb, aoff);
   }
   STAMP(5);
   __syncthreads();     // every wave is done with the staged activations; LDS becomes the reduce buffer
