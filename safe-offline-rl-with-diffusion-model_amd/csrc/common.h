@@ -61,6 +61,7 @@ struct ConvGeo {
   int TM, TN, TNp;
   int R, ldA, ld2, cbpt, KK1, KK, chunk;
   int nv, vlo, fh, hr;                            // valid input rows [vlo, vlo+nv) per candidate, front / total halo rows
+  int pm, fhk;                                    // position-major tiles (see Tile::pm): flag, front halo of the K loop
   // LDS carve, float offsets:  [slab | slab2 | yslab] aliased by [red | red2] ; res | colp | tbrow | pstat
   int oSlab2, oY, red1, oRes, oColp, oTb, oPstat, total;
   int c4n, c4n2, nValid4, nHalo4, nX24, nRes4, tn4;   // float4 counts of the staged streams
@@ -99,6 +100,10 @@ struct Tile {
   int MI, NI;                      // 16-row / 16-column sub-tiles per wave
   int NG, KS;                      // waves = NG (column groups) x KS (split of the reduction)
   int S;                           // whole samples per workgroup
+  // Position-major rows: MFMA row tile mi holds output position mi % Lout of 16 candidates (S a multiple of
+  // 16, 16*MI == S*Lout), so a (tile, tap) pair that would only read zero padding is skipped as a whole and the
+  // halo rows are never staged.  At L = 4 that is 14 of 20 (position, tap) pairs and half the LDS slab.
+  int pm = 0;
 };
 
 size_t conv_lds_bytes(const ConvP& p, const Tile& tl);

@@ -53,6 +53,13 @@ ConvGeo conv_make_geo(const ConvP& p, const Tile& tl) {
   g.nv = vhi - g.vlo;
   g.fh = g.vlo - li_min;
   g.hr = g.R - g.nv;
+  g.pm = tl.pm;
+  g.fhk = g.fh;
+  if (tl.pm) {                      // only the valid rows are staged; the K loop skips what would read the halo
+    g.R = g.nv;
+    g.fh = 0;
+    g.hr = 0;
+  }
   g.cbpt = p.Cin_p >> 4;
   g.KK1 = p.ntaps * g.cbpt;
   g.KK = g.KK1 + (p.x2 ? (p.Cin2_p >> 4) : 0);
@@ -109,7 +116,7 @@ static_assert(CVIEW_DW <= 256 && sizeof(ConvP) % 4 == 0 && CG0 % 4 == 0, "launch
 #define CP(f) dfield<decltype(ConvP::f), (int)(offsetof(ConvP, f) / 4)>(dv)
 #define CG(f) dfield<decltype(ConvGeo::f), CPW + (int)(offsetof(ConvGeo, f) / 4)>(dv)
 
-template <int MI, int NI, bool VEC>
+template <int MI, int NI, bool VEC, bool PM>
 __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b0, const int n0,
                                           const int tid, int t_uniform, const long long* tptr) {
   constexpr int WB = (NI == 1) ? (MI <= 2 ? 24 : 16) : 8;
@@ -377,14 +384,25 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
   STAMP(4);
 
   // ---- implicit GEMM on the f32 matrix cores --------------------------------------------
-  int rowA[MI], row2[MI];
+  constexpr bool pm = PM;            // position-major row tiles (Tile::pm), its own instantiation
+  const int fhk = CG(fhk);
+  int rowA[MI], row2[MI], jlo[MI], plo[MI], psb[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    int r = mi * 16 + lr;
-    int s = dLout.div(r), lo = r - s * Lout;
-    bool ok = s < S;
-    rowA[mi] = ok ? (s * R + lo * stride) * ldA + 4 * g : 4 * g;
-    row2[mi] = ok ? (s * Lout + lo) * ld2 + 4 * g : 4 * g;
+    if (pm) {                        // tile mi = output position mi % Lout of candidates 16*(mi / Lout) ..+15
+      const int sb = dLout.div(mi), lo = mi - sb * Lout, s = sb * 16 + lr;
+      plo[mi] = lo; psb[mi] = sb;
+      jlo[mi] = lo * stride - fhk;   // staged row of tap 0; tap tau reads row jlo + tau, valid in [0, nv)
+      rowA[mi] = (s * R + jlo[mi]) * ldA + 4 * g;
+      row2[mi] = (s * Lout + lo) * ld2 + 4 * g;
+    } else {
+      int r = mi * 16 + lr;
+      int s = dLout.div(r), lo = r - s * Lout;
+      bool ok = s < S;
+      plo[mi] = 0; psb[mi] = 0; jlo[mi] = 0;
+      rowA[mi] = ok ? (s * R + lo * stride) * ldA + 4 * g : 4 * g;
+      row2[mi] = ok ? (s * Lout + lo) * ld2 + 4 * g : 4 * g;
+    }
   }
   f32x4 acc[MI][NI], acc2[MI][NI];
 #pragma unroll
@@ -395,21 +413,37 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
       acc2[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   const FastDiv dCb(cbpt, CG(mCbpt));
-  auto kstep = [&](int u, int kk, int& cb, int& aoff) {
+  auto kstep = [&](int u, int kk, int& tau, int& cb, int& aoff) {
     if (kk < k_end) {
       f32x4 a[MI];
       if (kk < KK1) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        if constexpr (PM) {
+          // a (tile, tap) pair whose input row is zero padding is skipped as a whole (wave-uniform)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
+            if ((unsigned)(jlo[mi] + tau) < (unsigned)nv) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc[mi][ni], 0, 0, 0);
+          for (int mi = 0; mi < MI; ++mi)
+            if ((unsigned)(jlo[mi] + tau) < (unsigned)nv) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc[mi][ni], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[u][ni][j], acc[mi][ni], 0, 0, 0);
+        }
         aoff += 16;
-        if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
+        if (++cb == cbpt) { cb = 0; ++tau; aoff += ldA - cbpt * 16; }
       } else {
         const int a2 = (kk - KK1) * 16;
 #pragma unroll
@@ -429,17 +463,17 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
       int tau = dCb.div(base), cb = base - tau * cbpt;
       int aoff = tau * ldA + cb * 16;
 #pragma unroll
-      for (int u = 0; u < HB; ++u) kstep(u, base + u, cb, aoff);
+      for (int u = 0; u < HB; ++u) kstep(u, base + u, tau, cb, aoff);
       wload(0, base + WB);
 #pragma unroll
-      for (int u = HB; u < WB; ++u) kstep(u, base + u, cb, aoff);
+      for (int u = HB; u < WB; ++u) kstep(u, base + u, tau, cb, aoff);
       wload(HB, base + WB + HB);
     }
   } else {
     int tau = dCb.div(k_begin), cb = k_begin - tau * cbpt;
     int aoff = tau * ldA + cb * 16;
 #pragma unroll
-    for (int u = 0; u < WB; ++u) kstep(u, k_begin + u, cb, aoff);
+    for (int u = 0; u < WB; ++u) kstep(u, k_begin + u, tau, cb, aoff);
   }
   STAMP(5);
   __syncthreads();     // every wave is done with the staged activations; LDS becomes the reduce buffer
@@ -455,7 +489,8 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          int o = ks * kstride + (mi * 16 + g * 4 + q) * TNp + (ng * NI + ni) * 16 + lr;
+          const int row = pm ? (psb[mi] * 16 + g * 4 + q) * Lout + plo[mi] : mi * 16 + g * 4 + q;
+          int o = ks * kstride + row * TNp + (ng * NI + ni) * 16 + lr;
           red[o] = acc[mi][ni][q];
           if (has2) red2[o] = acc2[mi][ni][q];
         }
@@ -568,7 +603,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
   STAMP(9);
 }
 
-template <int MI, int NI, bool VEC>
+template <int MI, int NI, bool VEC, bool PM>
 __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef const __attribute__((address_space(4))) unsigned* kargp;
@@ -584,10 +619,10 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L) {
   // blockIdx.x = column tile, blockIdx.y = candidate group: workgroups are dealt to the 8 XCDs round-robin by
   // linear id, so the workgroups that share a weight slice land on the same XCD (one L2 fetches the slice
   // instead of all eight; the activations are tiny)
-  conv_body<MI, NI, VEC>(dv, smem, blockIdx.y * CG(S), blockIdx.x * CG(TN), threadIdx.x, CP(t_uniform), CP(t));
+  conv_body<MI, NI, VEC, PM>(dv, smem, blockIdx.y * CG(S), blockIdx.x * CG(TN), threadIdx.x, CP(t_uniform), CP(t));
 }
 
-template <int MI, int NI>
+template <int MI, int NI, bool PM>
 static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st) {
   const ConvP& p = L.p[0];
   ConvLaunch LL = L;
@@ -597,33 +632,35 @@ static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hip
   dim3 block(64 * tl.NG * tl.KS);
   bool vec = conv_vec_ok(L.p[0]) && (nz < 2 || conv_vec_ok(L.p[1]));
   if (vec)
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true>), grid, block, lds, st, LL);
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM>), grid, block, lds, st, LL);
   else
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, false>), grid, block, lds, st, LL);
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, false, PM>), grid, block, lds, st, LL);
   return hipGetLastError();
 }
+
+// the shapes the kernel is instantiated for: every (MI, NI) row-major; position-major where 16*MI == S*Lout can hold
+#define TREBI_TILES(X) X(1, 1, false) X(2, 1, false) X(4, 1, false) X(8, 1, false) X(1, 2, false) X(2, 2, false) \
+  X(4, 2, false) X(2, 1, true) X(4, 1, true) X(8, 1, true) X(2, 2, true) X(4, 2, true)
 
 // Dynamic LDS above 64 KiB has to be opted into per kernel (once per device, at context creation).
 hipError_t conv_init_device() {
   hipError_t e = hipSuccess;
-#define TREBI_ATTR(mi, ni)                                                                   \
+#define TREBI_ATTR(mi, ni, pm)                                                                 \
   if (e == hipSuccess)                                                                       \
-    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, true>,                     \
+    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, true, pm>,                 \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
   if (e == hipSuccess)                                                                       \
-    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, false>,                    \
+    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, false, pm>,                \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  TREBI_ATTR(1, 1) TREBI_ATTR(2, 1) TREBI_ATTR(4, 1) TREBI_ATTR(8, 1)
-  TREBI_ATTR(1, 2) TREBI_ATTR(2, 2) TREBI_ATTR(4, 2)
+  TREBI_TILES(TREBI_ATTR)
 #undef TREBI_ATTR
   return e;
 }
 
 hipError_t launch_conv(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st) {
-#define TREBI_CASE(mi, ni) \
-  if (tl.MI == mi && tl.NI == ni) return launch_conv_t<mi, ni>(L, nz, tl, st);
-  TREBI_CASE(1, 1) TREBI_CASE(2, 1) TREBI_CASE(4, 1) TREBI_CASE(8, 1)
-  TREBI_CASE(1, 2) TREBI_CASE(2, 2) TREBI_CASE(4, 2)
+#define TREBI_CASE(mi, ni, posmajor) \
+  if (tl.MI == mi && tl.NI == ni && (tl.pm != 0) == posmajor) return launch_conv_t<mi, ni, posmajor>(L, nz, tl, st);
+  TREBI_TILES(TREBI_CASE)
 #undef TREBI_CASE
   return hipErrorInvalidValue;
 }

@@ -868,6 +868,8 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
   const int R = (op.Lout - 1) * op.stride + op.ntaps;
   Tile best{};
   double best_cost = -1;
+  static const bool pm_on = !(getenv("TREBI_PM") && atoi(getenv("TREBI_PM")) == 0);
+  static const int pm_min_b = getenv("TREBI_PM_MINB") ? atoi(getenv("TREBI_PM_MINB")) : 512;          // diagnostics: position-major tiles off
   const int S0 = Lout >= 16 ? 1 : 16 / Lout;
   for (int S = S0; S * Lout <= 128 && (S == S0 || S <= B); S *= 2) {
     const int MI = mi_for(S);
@@ -878,21 +880,43 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
         if (units % tu || tu % tnu) continue;
         if (op.osplit && op.osplit % (16 * tu)) continue;
         int KS = std::max(1, std::min(8 / NG, std::max(1, KK / 4)));
-        Tile t{MI, NI, NG, KS, S};
-        const size_t lds = conv_lds_bytes(q, t);
-        if (lds > 160 * 1024) continue;
-        const long wgs = (long)((B + S - 1) / S) * (units / tu) * nz;
-        const long rounds = (wgs + 255) / 256;
-        const int chunk = (KK + KS - 1) / KS;
-        const double mfma = 32.0 * 4 * MI * NI * chunk;                  // cycles of one wave's matrix work
-        const double simd = mfma * std::max(1.0, NG * KS / 4.0);         // waves of a SIMD share its matrix core
-        const double nthr = 64.0 * NG * KS;
-        const double stage = 30.0 * ((double)S * R * op.Cin_p / 4 * (op.pro ? 3 : 1) +
-                                     (double)S * Lout * op.Cin2_p / 4) / nthr;
-        const double epi = 60.0 * (16.0 * MI * 16 * tu / 4) / nthr;
-        const double wload = 8.0 * chunk * NI;                           // issue + latency share of the weight stream
-        const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; }
+        for (int pm = 0; pm <= 1; ++pm) {
+          Tile t{MI, NI, NG, KS, S};
+          t.pm = pm;
+          double frac = 1.0;                          // share of (position, tap) pairs that touch real input rows
+          int rows = R;
+          if (pm) {
+            if (!pm_on || B < pm_min_b || S % 16 || S * Lout != 16 * MI) continue;
+            const ConvGeo g0 = conv_make_geo(q, Tile{MI, NI, NG, KS, S});
+            if (g0.hr == 0) continue;                 // no zero padding to skip
+            int valid = 0;
+            for (int lo = 0; lo < Lout; ++lo)
+              for (int tau = 0; tau < op.ntaps; ++tau) {
+                const int j = lo * op.stride + tau;
+                valid += (j >= g0.fh && j < g0.fh + g0.nv);
+              }
+            const double k1 = (double)op.ntaps * op.Cin_p, k2 = op.Cin2_p;
+            frac = (k1 * valid / (double)(Lout * op.ntaps) + k2) / (k1 + k2);
+            rows = g0.nv;
+          }
+          const size_t lds = conv_lds_bytes(q, t);
+          if (lds > 160 * 1024) continue;
+          const long wgs = (long)((B + S - 1) / S) * (units / tu) * nz;
+          const long rounds = (wgs + 255) / 256;
+          const int chunk = (KK + KS - 1) / KS;
+          // position-major tiles issue each tile's 4 MFMAs back to back behind a branch: with one column tile per
+          // wave (NI == 1) they form a dependent chain (40 instead of 32 cycles each) -- measured, not modelled finer
+          const double pmk = pm ? (NI == 1 ? 1.25 : 1.05) : 1.0;
+          const double mfma = 32.0 * 4 * MI * NI * chunk * frac * pmk;     // cycles of one wave's matrix work
+          const double simd = mfma * std::max(1.0, NG * KS / 4.0);         // waves of a SIMD share its matrix core
+          const double nthr = 64.0 * NG * KS;
+          const double stage = 30.0 * ((double)S * rows * op.Cin_p / 4 * (op.pro ? 3 : 1) +
+                                       (double)S * Lout * op.Cin2_p / 4) / nthr;
+          const double epi = 60.0 * (16.0 * MI * 16 * tu / 4) / nthr;
+          const double wload = 8.0 * chunk * NI;                           // issue + latency share of the weight stream
+          const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload);
+          if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; }
+        }
       }
     }
   }
@@ -1359,7 +1383,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
     st.flops = op.flops * B * nz;
     {
       char tb[96];
-      snprintf(tb, sizeof tb, " MI%d NI%d NG%d KS%d S%d grid %dx%d", st.tl.MI, st.tl.NI, st.tl.NG, st.tl.KS, st.tl.S,
+      snprintf(tb, sizeof tb, " MI%d NI%d NG%d KS%d S%d%s grid %dx%d", st.tl.MI, st.tl.NI, st.tl.NG, st.tl.KS, st.tl.S, st.tl.pm ? " pm" : "",
                (B + st.tl.S - 1) / st.tl.S, op.Npad / (16 * st.tl.NI * st.tl.NG));
       st.name = op.name + (op.pro ? " (bwd)" : "") + tb;
     }
