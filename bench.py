@@ -54,6 +54,26 @@ def build_models(device):
     return diff, guide, cguide, (sd_u, sd_r, sd_c)
 
 
+def unet_utilisation(unet, device, batch=8192, iters=10):
+    """north_star's second target: matrix-core utilisation of the TemporalUnet conv kernels where they are not
+    latency-bound -- the UNet forward alone at config 4's per-GPU size (8192 candidates), algorithmic FLOPs (zero-padding
+    taps excluded) over HIP-event time on the launch stream, against the fp32 matrix peak."""
+    x = torch.randn(batch, H, OBS + ACT, device=device)
+    t = torch.full((batch,), 5, device=device, dtype=torch.long)
+    for _ in range(2):
+        unet(x, None, t)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        unet(x, None, t)
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / iters
+    tf = unet.flops() * batch / (ms * 1e-3) / 1e12
+    return {'workload': f'TemporalUnet forward alone, {batch} candidates, dim_mults {tuple(MULTS)}', 'ms': ms,
+            'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F32_MFMA_TFLOPS}
+
+
 def cpu_baseline(sds, B, thr, runs=2):
     """The numpy oracle (a port of the reference path, oracle/trebi_oracle.py) on this box's host cores:
     the same workload (B candidates, full 20-step constrained loop), `runs` times."""
@@ -94,6 +114,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--guide-steps', type=int, default=PLAN_KW['n_guide_steps'],
                     help='n_guide_steps (headline 2; SURVEY 8d also asks for 1)')
+    ap.add_argument('--no-unet-util', action='store_true', help='skip the large-batch UNet utilisation measurement')
     ap.add_argument('--skip-dead-evals', action='store_true',
                     help='also drop guide evaluations whose result cannot reach an output (not the default)')
     args = ap.parse_args()
@@ -213,6 +234,8 @@ def main():
                          'algorithmic_flops_per_launch': flops_per_launch,
                          'eager_loop_ms': prof['loop_us'] / 1e3},
         }
+        if world == 1 and not args.no_unet_util:
+            out['unet_mfma'] = unet_utilisation(diff.model, device)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sds, B, thr)
         print(json.dumps(out), flush=True)
