@@ -19,7 +19,10 @@ def _mk(cls, sd, *a, **k):
     return net
 
 
-@pytest.mark.parametrize('name,total', [('hopper', 512), ('walker148', 8192), ('halfcheetah', 130)])
+@pytest.mark.parametrize('name,total', [('hopper', 512), ('walker148', 8192), ('halfcheetah', 130),
+                                        # position-major tiles (>= 512 candidates) on the other shapes, ragged tails
+                                        ('halfcheetah', 601), ('halfcheetah_h4', 1030), ('pendulum_h128', 515),
+                                        ('pendulum', 4100)])
 def test_copies_of_golden_candidates(name, total):
     from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
     from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
