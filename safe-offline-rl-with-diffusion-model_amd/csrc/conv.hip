@@ -164,6 +164,14 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
   // waits are exact counts instead of vmcnt(0).
   constexpr int HB = WB / 2;
   const bool multi = k_end - k_begin > WB;
+  // The planning-batch shape (one 16x16 tile per wave, the whole chunk in registers): straight-line step sequences
+  // entered by one branch per block of BS steps, so every A operand of a block is requested from LDS before its
+  // first MFMA (a branch per step exposed the LDS latency at every step), and two accumulators per source, one for
+  // even and one for odd slots (a single chain pays the 40-cycle dependent-MFMA latency instead of the 32-cycle issue).
+  constexpr bool STR = MI == 1 && NI == 1 && !PM;
+  constexpr int BS = 8;
+  const int n1 = (k_end < KK1 ? k_end : KK1) > k_begin ? (k_end < KK1 ? k_end : KK1) - k_begin : 0;   // first-source steps
+  const int n2 = k_end - k_begin - n1;                                                              // second-source steps
   const int k_last = KK - 1;
   auto wload = [&](int u0, int kbase) {
 #pragma unroll
@@ -178,6 +186,14 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
   if (multi) {
     wload(0, k_begin);
     wload(HB, k_begin + HB);
+  } else if constexpr (STR) {
+    // slot u < n1: step k_begin + u of the first source; the LAST n2 slots: the second source's steps counted
+    // from the end (slot WB-1-j <-> step k_end-1-j), so that both step sequences below index registers statically
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+      const int kk = u < n1 ? k_begin + u : (u >= WB - n2 ? k_end - WB + u : -1);
+      if (kk >= 0) wreg[u][0] = gld4(pw + (unsigned)kk * wstep + wlane);
+    }
   } else {
     const float* wu = pw + (size_t)k_begin * wstep;
 #pragma unroll
@@ -469,6 +485,61 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
       for (int u = HB; u < WB; ++u) kstep(u, base + u, tau, cb, aoff);
       wload(HB, base + WB + HB);
     }
+  } else if constexpr (STR) {
+    f32x4 accb = {0.f, 0.f, 0.f, 0.f}, acc2b = {0.f, 0.f, 0.f, 0.f};
+#define TREBI_MF(u, SLOT, EVEN, ODD)                                                                        \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+    if ((u) & 1) ODD = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], wreg[SLOT][0][j], ODD, 0, 0, 0);       \
+    else EVEN = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], wreg[SLOT][0][j], EVEN, 0, 0, 0);             \
+  }
+#define TREBI_SEQ(n, SLOT, EVEN, ODD)                                       \
+  switch (n) {                                                              \
+    default: TREBI_MF(7, SLOT(7), EVEN, ODD) [[fallthrough]];               \
+    case 7: TREBI_MF(6, SLOT(6), EVEN, ODD) [[fallthrough]];                \
+    case 6: TREBI_MF(5, SLOT(5), EVEN, ODD) [[fallthrough]];                \
+    case 5: TREBI_MF(4, SLOT(4), EVEN, ODD) [[fallthrough]];                \
+    case 4: TREBI_MF(3, SLOT(3), EVEN, ODD) [[fallthrough]];                \
+    case 3: TREBI_MF(2, SLOT(2), EVEN, ODD) [[fallthrough]];                \
+    case 2: TREBI_MF(1, SLOT(1), EVEN, ODD) [[fallthrough]];                \
+    case 1: TREBI_MF(0, SLOT(0), EVEN, ODD)                                 \
+  }
+#pragma unroll
+    for (int blk = 0; blk < WB / BS; ++blk) {           // first source: slots blk*BS + u
+      const int nb = n1 - blk * BS;
+      if (nb > 0) {
+        const int kb = k_begin + blk * BS;
+        int tau = dCb.div(kb), cb = kb - tau * cbpt;
+        int aoff = rowA[0] + tau * ldA + cb * 16;
+        const int aoff0 = aoff;
+        f32x4 a[BS];
+#pragma unroll
+        for (int u = 0; u < BS; ++u) {
+          a[u] = *(const f32x4*)&slab[u < nb ? aoff : aoff0];     // unused slots: any valid address
+          aoff += 16;
+          if (++cb == cbpt) { cb = 0; aoff += ldA - cbpt * 16; }
+        }
+#define TREBI_SLOT1(u) (blk * BS + (u))
+        TREBI_SEQ(nb, TREBI_SLOT1, acc[0][0], accb)
+#undef TREBI_SLOT1
+      }
+    }
+#pragma unroll
+    for (int blk = 0; blk < WB / BS; ++blk) {           // second source, from the end: slot WB-1-(blk*BS+u)
+      const int nb = n2 - blk * BS;
+      if (nb > 0) {
+        const int a2 = row2[0] + (k_end - 1 - blk * BS - KK1) * 16;
+        f32x4 a[BS];
+#pragma unroll
+        for (int u = 0; u < BS; ++u) a[u] = *(const f32x4*)&slab2[u < nb ? a2 - 16 * u : a2];
+#define TREBI_SLOT2(u) (WB - 1 - blk * BS - (u))
+        TREBI_SEQ(nb, TREBI_SLOT2, acc2[0][0], acc2b)
+#undef TREBI_SLOT2
+      }
+    }
+#undef TREBI_SEQ
+#undef TREBI_MF
+    acc[0][0] += accb;
+    acc2[0][0] += acc2b;
   } else {
     int tau = dCb.div(k_begin), cb = k_begin - tau * cbpt;
     int aoff = tau * ldA + cb * 16;
