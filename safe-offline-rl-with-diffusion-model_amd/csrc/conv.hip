@@ -116,34 +116,26 @@ static_assert(CVIEW_DW <= 256 && sizeof(ConvP) % 4 == 0 && CG0 % 4 == 0, "launch
 #define CP(f) dfield<decltype(ConvP::f), (int)(offsetof(ConvP, f) / 4)>(dv)
 #define CG(f) dfield<decltype(ConvGeo::f), CPW + (int)(offsetof(ConvGeo, f) / 4)>(dv)
 
+// The fields the weight preload needs travel as separate kernel arguments in front of the launch descriptor and are
+// PRELOADED into scalar registers by the command processor (-mllvm -amdgpu-kernarg-preload-count, see the
+// Makefile): the wave requests its weights at once, while the descriptor (read from the kernel-argument segment,
+// a cold ~0.9 us fetch after every kernel boundary) is still on its way.
+struct ConvPre {
+  const float* w;                   // this net's packed weights
+  int Npad, TN, NG;
+  unsigned mNG;
+  int chunk, KK, KK1;
+};
+
 template <int MI, int NI, bool VEC, bool PM>
-__device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b0, const int n0,
-                                          const int tid, int t_uniform, const long long* tptr) {
+__device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float* smem, const int by, const int n0,
+                                          const int tid) {
   constexpr int WB = (NI == 1) ? (MI <= 2 ? 24 : 16) : 8;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // ---- every argument field used below, read once and pinned in scalar registers ----------------
-  const float* px = CP(x);  const float* pw = CP(w);  float* pout = CP(out);
-  int ldx = CP(ldx), Cin = CP(Cin), Lin = CP(Lin), Lout = CP(Lout), stride = CP(stride), B = CP(B), N = CP(N), Npad = CP(Npad);
-  int S = CG(S), NG = CG(NG), KS = CG(KS), nthr = CG(nthr), TM = CG(TM), TN = CG(TN), TNp = CG(TNp), R = CG(R), ldA = CG(ldA),
-      ld2 = CG(ld2);
-  int cbpt = CG(cbpt), KK1 = CG(KK1), KK = CG(KK), chunk = CG(chunk), nv = CG(nv), fh = CG(fh);
-  PIN(px); PIN(pw); PIN(pout); PIN(ldx); PIN(Cin); PIN(Lin); PIN(Lout); PIN(stride); PIN(B); PIN(N); PIN(Npad);
-  PIN(S); PIN(NG); PIN(KS); PIN(nthr); PIN(TM); PIN(TN); PIN(TNp); PIN(R); PIN(ldA); PIN(ld2);
-  PIN(cbpt); PIN(KK1); PIN(KK); PIN(chunk); PIN(nv); PIN(fh);
-  const bool has2 = CP(x2) != nullptr, haspro = CP(pro) != 0, hasres = CP(res) != nullptr, hastb = CP(tbias) != nullptr,
-             hasgn = CP(gn) != 0;
-  const bool active = tid < nthr;
-  float* slab = smem;
-  float* slab2 = smem + CG(oSlab2);
-  float* yslab = smem + CG(oY);
-  float* restile = smem + CG(oRes);
-  float* colp = smem + CG(oColp);          // [4][TN]: bias, gamma, beta, bias2
-  float* tbrow = smem + CG(oTb);           // [S][TN]
-  float* pstat = smem + CG(oPstat);        // [S*8][2] mean, rstd of the producing block
-  const FastDiv dLout(Lout, CG(mLout)), dTN4(CG(tn4), CG(mTN4)), dTN(TN, CG(mTN));
-  const int nvs = (B - b0 < S) ? B - b0 : S;       // candidates of this tile that exist
+  const float* pw = pre.w;
+  const int Npad = pre.Npad, TN = pre.TN, NG = pre.NG, chunk = pre.chunk, KK = pre.KK, KK1 = pre.KK1;
+  constexpr bool active = true;     // the launch has exactly 64*NG*KS threads
   STAMP(0);
 
   // ---- wave geometry + weight preload (registers) -------------------------------------------
@@ -151,7 +143,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
   // reduction index is permuted so that lane-group g = l>>4 owns channels 16*kk+4g .. +3 of
   // step kk and the four MFMAs of the step consume one float4 of A (LDS) and one of B (global).
   const int g = lane >> 4, lr = lane & 15;
-  const int ks = FastDiv(NG, CG(mNG)).div(wave), ng = wave - ks * NG;
+  const int ks = FastDiv(NG, pre.mNG).div(wave), ng = wave - ks * NG;
   const int k_begin = active ? ks * chunk : 0;
   const int k_end = active ? ((k_begin + chunk < KK) ? k_begin + chunk : KK) : 0;
   // uniform base (scalar registers) + one 32-bit per-lane offset: the loads need no per-lane 64-bit math
@@ -206,6 +198,29 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
     }
   }
   STAMP(1);
+
+  // ---- every other argument field used below, read once from the descriptor and pinned in scalar registers ----
+  const float* px = CP(x);  float* pout = CP(out);
+  int ldx = CP(ldx), Cin = CP(Cin), Lin = CP(Lin), Lout = CP(Lout), stride = CP(stride), B = CP(B), N = CP(N);
+  int S = CG(S), KS = CG(KS), nthr = CG(nthr), TM = CG(TM), TNp = CG(TNp), R = CG(R), ldA = CG(ldA), ld2 = CG(ld2);
+  int cbpt = CG(cbpt), nv = CG(nv), fh = CG(fh);
+  PIN(px); PIN(pout); PIN(ldx); PIN(Cin); PIN(Lin); PIN(Lout); PIN(stride); PIN(B); PIN(N);
+  PIN(S); PIN(KS); PIN(nthr); PIN(TM); PIN(TNp); PIN(R); PIN(ldA); PIN(ld2);
+  PIN(cbpt); PIN(nv); PIN(fh);
+  const bool has2 = CP(x2) != nullptr, haspro = CP(pro) != 0, hasres = CP(res) != nullptr, hastb = CP(tbias) != nullptr,
+             hasgn = CP(gn) != 0;
+  const int t_uniform = CP(t_uniform);
+  const long long* tptr = CP(t);
+  const int b0 = by * S;
+  float* slab = smem;
+  float* slab2 = smem + CG(oSlab2);
+  float* yslab = smem + CG(oY);
+  float* restile = smem + CG(oRes);
+  float* colp = smem + CG(oColp);          // [4][TN]: bias, gamma, beta, bias2
+  float* tbrow = smem + CG(oTb);           // [S][TN]
+  float* pstat = smem + CG(oPstat);        // [S*8][2] mean, rstd of the producing block
+  const FastDiv dLout(Lout, CG(mLout)), dTN4(CG(tn4), CG(mTN4)), dTN(TN, CG(mTN));
+  const int nvs = (B - b0 < S) ? B - b0 : S;       // candidates of this tile that exist
 
   // ---- stage everything this workgroup reads from global: all loads first, then the LDS writes ----
   if (active) {
@@ -674,11 +689,13 @@ __device__ __forceinline__ void conv_body(const DV& dv, float* smem, const int b
   STAMP(9);
 }
 
+constexpr int CPRE_DW = 12;          // dwords of kernel arguments in front of the descriptor (11 used + alignment)
 template <int MI, int NI, bool VEC, bool PM>
-__global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L) {
+__global__ __launch_bounds__(512) void conv_gemm_kernel(const float* w0, const float* w1, int Npad, int TN, int NG,
+                                                        unsigned mNG, int chunk, int KK, int KK1, ConvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef const __attribute__((address_space(4))) unsigned* kargp;
-  kargp ka = (kargp)__builtin_amdgcn_kernarg_segment_ptr();      // L is the only argument: offset 0
+  kargp ka = (kargp)__builtin_amdgcn_kernarg_segment_ptr() + CPRE_DW;
   const int lane = threadIdx.x & 63, z = blockIdx.z;
   DV dv;
 #pragma unroll
@@ -687,10 +704,11 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvLaunch L) {
     const int src = j < CPW ? z * CPW + j : CG0 / 4 + (j - CPW);
     dv.v[k] = j < CVIEW_DW ? ka[src] : 0u;
   }
+  const ConvPre pre{z ? w1 : w0, Npad, TN, NG, mNG, chunk, KK, KK1};
   // blockIdx.x = column tile, blockIdx.y = candidate group: workgroups are dealt to the 8 XCDs round-robin by
   // linear id, so the workgroups that share a weight slice land on the same XCD (one L2 fetches the slice
   // instead of all eight; the activations are tiny)
-  conv_body<MI, NI, VEC, PM>(dv, smem, blockIdx.y * CG(S), blockIdx.x * CG(TN), threadIdx.x, CP(t_uniform), CP(t));
+  conv_body<MI, NI, VEC, PM>(dv, pre, smem, blockIdx.y, blockIdx.x * TN, threadIdx.x);
 }
 
 template <int MI, int NI, bool PM>
@@ -702,10 +720,16 @@ static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hip
   dim3 grid(p.Npad / (16 * tl.NI * tl.NG), (p.B + tl.S - 1) / tl.S, nz);
   dim3 block(64 * tl.NG * tl.KS);
   bool vec = conv_vec_ok(L.p[0]) && (nz < 2 || conv_vec_ok(L.p[1]));
+  const ConvGeo& g = LL.g;
+  const float* w0 = L.p[0].w;
+  const float* w1 = L.p[nz > 1 ? 1 : 0].w;
+  static_assert(offsetof(ConvLaunch, p) == 0 && alignof(ConvLaunch) == 8, "descriptor offset in the kernel arguments");
   if (vec)
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM>), grid, block, lds, st, LL);
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
+                       g.chunk, g.KK, g.KK1, LL);
   else
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, false, PM>), grid, block, lds, st, LL);
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, false, PM>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
+                       g.chunk, g.KK, g.KK1, LL);
   return hipGetLastError();
 }
 
