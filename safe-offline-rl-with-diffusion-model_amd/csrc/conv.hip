@@ -147,7 +147,10 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
   const int k_begin = active ? ks * chunk : 0;
   const int k_end = active ? ((k_begin + chunk < KK) ? k_begin + chunk : KK) : 0;
   // uniform base (scalar registers) + one 32-bit per-lane offset: the loads need no per-lane 64-bit math
-  const unsigned wlane = (unsigned)((g * Npad + n0 + ng * NI * 16 + lr) * 4);
+  // 24-bit multiply on purpose: for a 32-bit multiply-add the compiler emits v_mad_u64_u32 with an undefined high
+  // addend, allocates that to the register the descriptor is being loaded into, and then waits for the descriptor
+  // (vmcnt(0)) in front of the weight loads
+  const unsigned wlane = (__umul24((unsigned)g, (unsigned)Npad) + (unsigned)(n0 + ng * NI * 16 + lr)) * 4u;
   const unsigned wstep = (unsigned)Npad * 16u;     // floats per kk step
   f32x4 wreg[WB][NI];
   // A reduction longer than one register block (large batches: no split-K) is software-pipelined in half
