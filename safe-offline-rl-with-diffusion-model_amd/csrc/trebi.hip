@@ -879,7 +879,11 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
         const int tu = NI * NG;                     // tile width in 16-column units
         if (units % tu || tu % tnu) continue;
         if (op.osplit && op.osplit % (16 * tu)) continue;
-        int KS = std::max(1, std::min(8 / NG, std::max(1, KK / 4)));
+        const int KS0 = std::max(1, std::min(8 / NG, std::max(1, KK / 4)));
+        // smaller workgroups (less split-K) leave room for several per CU: at large batches the narrow layers' lifetime
+        // is all latency, which co-resident workgroups overlap (~200 VGPRs: 8 waves per CU)
+        static const bool occ_on = !(getenv("TREBI_OCC") && atoi(getenv("TREBI_OCC")) == 0);
+        for (int KS = KS0; KS >= 1; KS = (KS > 1 && occ_on && B >= 512) ? KS / 2 : 0)
         for (int pm = 0; pm <= 1; ++pm) {
           Tile t{MI, NI, NG, KS, S};
           t.pm = pm;
@@ -902,13 +906,14 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
           const size_t lds = conv_lds_bytes(q, t);
           if (lds > 160 * 1024) continue;
           const long wgs = (long)((B + S - 1) / S) * (units / tu) * nz;
-          const long rounds = (wgs + 255) / 256;
+          const int occ = (occ_on && B >= 512) ? std::max(1, std::min(8 / (NG * KS), (int)(160 * 1024 / std::max<size_t>(lds, 1)))) : 1;
+          const long rounds = (wgs + 256 * occ - 1) / (256 * occ);
           const int chunk = (KK + KS - 1) / KS;
           // position-major tiles issue each tile's 4 MFMAs back to back behind a branch: with one column tile per
           // wave (NI == 1) they form a dependent chain (40 instead of 32 cycles each) -- measured, not modelled finer
           const double pmk = pm ? (NI == 1 ? 1.25 : 1.05) : 1.0;
           const double mfma = 32.0 * 4 * MI * NI * chunk * frac * pmk;     // cycles of one wave's matrix work
-          const double simd = mfma * std::max(1.0, NG * KS / 4.0);         // waves of a SIMD share its matrix core
+          const double simd = mfma * std::max(1.0, occ * NG * KS / 4.0);   // waves of a SIMD share its matrix core
           const double nthr = 64.0 * NG * KS;
           const double stage = 30.0 * ((double)S * rows * op.Cin_p / 4 * (op.pro ? 3 : 1) +
                                        (double)S * Lout * op.Cin2_p / 4) / nthr;
