@@ -883,7 +883,8 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
         // smaller workgroups (less split-K) leave room for several per CU: at large batches the narrow layers' lifetime
         // is all latency, which co-resident workgroups overlap (~200 VGPRs: 8 waves per CU)
         static const bool occ_on = !(getenv("TREBI_OCC") && atoi(getenv("TREBI_OCC")) == 0);
-        for (int KS = KS0; KS >= 1; KS = (KS > 1 && occ_on && B >= 512) ? KS / 2 : 0)
+        static const int occ_min_b = getenv("TREBI_OCC_MINB") ? atoi(getenv("TREBI_OCC_MINB")) : 512;
+        for (int KS = KS0; KS >= 1; KS = (KS > 1 && occ_on && B >= occ_min_b) ? KS / 2 : 0)
         for (int pm = 0; pm <= 1; ++pm) {
           Tile t{MI, NI, NG, KS, S};
           t.pm = pm;
@@ -906,7 +907,7 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
           const size_t lds = conv_lds_bytes(q, t);
           if (lds > 160 * 1024) continue;
           const long wgs = (long)((B + S - 1) / S) * (units / tu) * nz;
-          const int occ = (occ_on && B >= 512) ? std::max(1, std::min(8 / (NG * KS), (int)(160 * 1024 / std::max<size_t>(lds, 1)))) : 1;
+          const int occ = (occ_on && B >= occ_min_b) ? std::max(1, std::min(8 / (NG * KS), (int)(160 * 1024 / std::max<size_t>(lds, 1)))) : 1;
           const long rounds = (wgs + 256 * occ - 1) / (256 * occ);
           const int chunk = (KK + KS - 1) / KS;
           // position-major tiles issue each tile's 4 MFMAs back to back behind a branch: with one column tile per
