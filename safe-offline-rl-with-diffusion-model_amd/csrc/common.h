@@ -62,6 +62,7 @@ struct ConvGeo {
   int R, ldA, ld2, cbpt, KK1, KK, chunk;
   int nv, vlo, fh, hr;                            // valid input rows [vlo, vlo+nv) per candidate, front / total halo rows
   int pm, fhk;                                    // position-major tiles (see Tile::pm): flag, front halo of the K loop
+  int resg;                                       // identity residual read from global memory in the epilogue (no LDS tile)
   // LDS carve, float offsets:  [slab | slab2 | yslab] aliased by [red | red2] ; res | colp | tbrow | pstat
   int oSlab2, oY, red1, oRes, oColp, oTb, oPstat, total;
   int c4n, c4n2, nValid4, nHalo4, nX24, nRes4, tn4;   // float4 counts of the staged streams
@@ -104,6 +105,9 @@ struct Tile {
   // 16, 16*MI == S*Lout), so a (tile, tap) pair that would only read zero padding is skipped as a whole and the
   // halo rows are never staged.  At L = 4 that is 14 of 20 (position, tap) pairs and half the LDS slab.
   int pm = 0;
+  // Identity residual read straight from global memory in the epilogue instead of being staged as an LDS tile:
+  // costs a memory round trip there, frees 16*MI x (TN+4) floats -- what lets 16 candidates fit the backward layers.
+  int resg = 0;
 };
 
 size_t conv_lds_bytes(const ConvP& p, const Tile& tl);

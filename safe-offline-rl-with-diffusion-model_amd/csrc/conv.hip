@@ -71,7 +71,8 @@ ConvGeo conv_make_geo(const ConvP& p, const Tile& tl) {
   int red = g.red1 * (p.x2 ? 2 : 1), stage = nA + n2 + nY;
   int body = ((stage > red ? stage : red) + 3) & ~3;
   g.oRes = body;
-  g.oColp = g.oRes + (p.res ? g.TM * g.TNp : 0);
+  g.resg = (p.res && tl.resg) ? 1 : 0;
+  g.oColp = g.oRes + ((p.res && !g.resg) ? g.TM * g.TNp : 0);
   g.oTb = g.oColp + 4 * g.TN;
   g.oPstat = g.oTb + (p.tbias ? g.S * g.TN : 0);
   g.total = g.oPstat + (p.pro ? 2 * g.S * GN_GROUPS : 0);
@@ -266,7 +267,8 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
       const float* sp = CP(res) + ((unsigned)b0 * Lout + row) * (unsigned)CP(ldres) + n0 + 4 * c4;
       return CG(vecr) ? load4<true>(sp, left) : load4<false>(sp, left);
     };
-    if (hasres) {
+    const bool resl = hasres && !CG(resg);          // residual staged as an LDS tile
+    if (resl) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         if (tid + u * nthr < nRes4) rv[u] = res_item(tid + u * nthr, &ro[u]);
@@ -359,7 +361,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
         if (tid + u * nthr < S * TN) tbrow[tid + u * nthr] = tbv[u];
       for (int e = tid + 2 * nthr; e < S * TN; e += nthr) tbrow[e] = tb_load(e);
     }
-    if (hasres) {
+    if (resl) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         if (ro[u] >= 0) *(f32x4*)&restile[ro[u]] = rv[u];
@@ -591,7 +593,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
   const FastDiv dOs(CP(osplit) > 0 ? CP(osplit) : 1, CG(mOs));
   const int osplit = CP(osplit);
   const unsigned ldo = CP(ldo);
-  const bool veco = CG(veco) != 0;
+  const bool veco = CG(veco) != 0, resg = CG(resg) != 0;
   // finish 4 adjacent output columns: time bias, second-source sum, residual, store
   auto finish = [&](f32x4 v, int s, int row, int col) {
     const int o = row * TNp + col;
@@ -601,9 +603,16 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
       for (int k = 0; k < KS; ++k) v2 += *(const f32x4*)&red2[k * kstride + o];
       v += v2;
     }
-    if (hasres) v += *(const f32x4*)&restile[o];
     const int n = n0 + col;
     unsigned orow = (unsigned)b0 * Lout + row;
+    if (hasres) {
+      if (resg) {
+        const float* sp = CP(res) + orow * (unsigned)CP(ldres) + n;
+        v += CG(vecr) ? load4<true>(sp, N - n) : load4<false>(sp, N - n);
+      } else {
+        v += *(const f32x4*)&restile[o];
+      }
+    }
     float* dst;
     if (osplit > 0) {
       int ph = dOs.div(n);

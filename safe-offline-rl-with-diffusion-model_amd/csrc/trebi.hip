@@ -885,9 +885,11 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
         static const bool occ_on = !(getenv("TREBI_OCC") && atoi(getenv("TREBI_OCC")) == 0);
         static const int occ_min_b = getenv("TREBI_OCC_MINB") ? atoi(getenv("TREBI_OCC_MINB")) : 512;
         for (int KS = KS0; KS >= 1; KS = (KS > 1 && occ_on && B >= occ_min_b) ? KS / 2 : 0)
-        for (int pm = 0; pm <= 1; ++pm) {
+        for (int pm = 0; pm <= 1; ++pm)
+        for (int resg = 0; resg <= ((op.res.id != NONE && B >= 512) ? 1 : 0); ++resg) {
           Tile t{MI, NI, NG, KS, S};
           t.pm = pm;
+          t.resg = resg;
           double frac = 1.0;                          // share of (position, tap) pairs that touch real input rows
           int rows = R;
           if (pm) {
@@ -920,7 +922,7 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
                                        (double)S * Lout * op.Cin2_p / 4) / nthr;
           const double epi = 60.0 * (16.0 * MI * 16 * tu / 4) / nthr;
           const double wload = 8.0 * chunk * NI;                           // issue + latency share of the weight stream
-          const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload);
+          const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload + (resg ? 2500.0 : 0.0));
           if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; }
         }
       }
@@ -1389,7 +1391,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
     st.flops = op.flops * B * nz;
     {
       char tb[96];
-      snprintf(tb, sizeof tb, " MI%d NI%d NG%d KS%d S%d%s grid %dx%d", st.tl.MI, st.tl.NI, st.tl.NG, st.tl.KS, st.tl.S, st.tl.pm ? " pm" : "",
+      snprintf(tb, sizeof tb, " MI%d NI%d NG%d KS%d S%d%s%s grid %dx%d", st.tl.MI, st.tl.NI, st.tl.NG, st.tl.KS, st.tl.S, st.tl.pm ? " pm" : "", st.tl.resg ? " resg" : "",
                (B + st.tl.S - 1) / st.tl.S, op.Npad / (16 * st.tl.NI * st.tl.NG));
       st.name = op.name + (op.pro ? " (bwd)" : "") + tb;
     }
