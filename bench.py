@@ -54,6 +54,54 @@ def build_models(device):
     return diff, guide, cguide, (sd_u, sd_r, sd_c)
 
 
+def other_configs(device, steps=3):
+    """BASELINE configs 3 and 4 at their PER-GPU size (the driver's scaling runs use the headline config): whole planning
+    calls through the same ShardedPlanner path, synthetic seeded weights.  Reported next to the headline, not as `value`."""
+    from trebi_amd import spec, synth
+    from trebi_amd.parallel import ShardedPlanner
+    from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
+    from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
+    out = []
+    for name, obs, act, um, vm, B, kw in (
+            ('configs[2]: hopper-medium-v2 shapes, 4096 candidates / 8 GPUs', 11, 3, (1, 2, 4, 8), (1, 2, 4, 8), 512,
+             dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0)),
+            ('configs[3]: walker2d shapes, UNet dim_mults (1,4,8), 65536 candidates / 8 GPUs', 17, 6, (1, 4, 8),
+             (1, 2, 4, 8), 8192, dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0))):
+        D = obs + act
+
+        def mk(cls, shapes, seed, mults):
+            net = cls(H, D, 0, dim=DIM, dim_mults=mults)
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed).items()})
+            return net
+        dkw = dict(n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False)
+        unet = mk(TemporalUnet, spec.unet_param_shapes(H, D, DIM, um), 100, um)
+        diff = GaussianDiffusion(unet, H, obs, act, **dkw).to(device)
+        guide = ValueGuide(ValueDiffusion(mk(ValueFunction, spec.value_param_shapes(H, D, DIM, vm), 101, vm), H, obs, act,
+                                          **dkw)).to(device)
+        cguide = ValueGuide(ValueDiffusion(mk(ValueFunction, spec.value_param_shapes(H, D, DIM, vm), 102, vm), H, obs, act,
+                                           **dkw)).to(device)
+        o = torch.from_numpy(np.random.default_rng(1).standard_normal(obs).astype(np.float32)).to(device)
+        x_T = torch.randn(B, H, D, device=device, generator=torch.Generator(device).manual_seed(2))
+        x_T[:, 0, act:] = o
+        thr = float(cguide(x_T, None, torch.full((B,), T - 1, device=device, dtype=torch.long)).median())
+        planner = ShardedPlanner(diff)
+        run = lambda: planner.plan(o, B, H, fn, cost_threshold=thr, guide=guide, cost_guide=cguide, **kw)
+        run()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / steps
+        fl = T * (unet.flops() + 2 * kw['n_guide_steps'] * (guide._net().flops() + guide._net().flops(backward=True)))
+        tf = fl * B / dt / 1e12
+        out.append({'workload': f'{name}: {B} candidates on this GPU', 'trajectories_per_s': B / dt, 'ms_per_step': 1e3 * dt,
+                    'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F32_MFMA_TFLOPS})
+        del planner, diff, guide, cguide, unet
+        torch.cuda.empty_cache()
+    return out
+
+
 def unet_utilisation(unet, device, batch=8192, iters=10):
     """north_star's second target: matrix-core utilisation of the TemporalUnet conv kernels where they are not
     latency-bound -- the UNet forward alone at config 4's per-GPU size (8192 candidates), algorithmic FLOPs (zero-padding
@@ -236,6 +284,7 @@ def main():
         }
         if world == 1 and not args.no_unet_util:
             out['unet_mfma'] = unet_utilisation(diff.model, device)
+            out['other_configs'] = other_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sds, B, thr)
         print(json.dumps(out), flush=True)
