@@ -1764,7 +1764,7 @@ static int ensure_plans(trebi_sampler* s, float* x, float* values, float* costs)
   const char* e_maxb = getenv("TREBI_CHAIN_MAXB");
   const char* e_cs = getenv("TREBI_CHAIN_S");
   const int chain_max_b = e_maxb ? atoi(e_maxb) : 512;
-  const int chain_S = (e_chain && atoi(e_chain) == 0) || B > chain_max_b ? 0 : (e_cs ? atoi(e_cs) : (B <= 160 ? 1 : 2));
+  const int chain_S = (e_chain && atoi(e_chain) == 0) || B > chain_max_b ? 0 : (e_cs ? atoi(e_cs) : (B <= 160 ? 1 : B <= 448 ? 2 : 4));
   const int chain_max_n = e_maxn ? atoi(e_maxn) : 64;
   std::vector<RStage> tab;
   s->vf_grad.clear(); s->vf_nograd.clear(); s->unet_plan.clear();
