@@ -868,6 +868,7 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
   const int R = (op.Lout - 1) * op.stride + op.ntaps;
   Tile best{};
   double best_cost = -1;
+  std::vector<std::pair<double, Tile>> ranked;
   static const bool pm_on = !(getenv("TREBI_PM") && atoi(getenv("TREBI_PM")) == 0);
   static const int pm_min_b = getenv("TREBI_PM_MINB") ? atoi(getenv("TREBI_PM_MINB")) : 512;          // diagnostics: position-major tiles off
   const int S0 = Lout >= 16 ? 1 : 16 / Lout;
@@ -924,11 +925,17 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
           const double wload = 8.0 * chunk * NI;                           // issue + latency share of the weight stream
           const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload + (resg ? 2500.0 : 0.0));
           if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; }
+          ranked.push_back({cost, t});
         }
       }
     }
   }
   if (best_cost < 0) unsupported("layer %s needs more than 160 KiB of LDS", op.name.c_str());
+  static const int rank = getenv("TREBI_TILE_RANK") ? atoi(getenv("TREBI_TILE_RANK")) : 0;   // diagnostics: r-th best tile
+  if (rank > 0) {
+    std::stable_sort(ranked.begin(), ranked.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    return ranked[std::min<size_t>(rank, ranked.size() - 1)].second;
+  }
   return best;
 }
 
