@@ -253,7 +253,8 @@ def main():
         # figure is the committed rocprofv3 --pmc measurement of this same command (profiles/, tools/analyze_traffic.py)
         traffic = None
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_d_hbm_traffic.json')) as f:
+            import glob
+            with open(sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')))[-1]) as f:   # newest round
                 traffic = json.load(f)['conv_gemm_kernel']['hbm_bytes_per_launch']
         except Exception:
             pass
