@@ -174,7 +174,12 @@ def _noise_for(x, t, noise):
 def _ddpm_step(model, x, cond, t, noise):
     """p_mean_variance + posterior sample + re-conditioning, fused (diffusion.py:166-185, functions.py:131-137)."""
     B, H, D = x.shape
-    x0 = model.model(x, cond, t)
+    # x_recon exactly as p_mean_variance builds it (diffusion.py:176-181): identity for predict_epsilon=False /
+    # clip_denoised=False (the planning configs), otherwise the reference's two torch expressions on the net output
+    x0 = model.predict_start_from_noise(x, t=t, noise=model.model(x, cond, t))
+    if model.clip_denoised:
+        x0 = x0.clamp(-1., 1.)
+    x0 = x0.contiguous()
     d, keys = _step_desc(model, cond)
     d.horizon = H
     cts = _cond_tensors(cond, keys, B, model.observation_dim, x.device)
@@ -240,16 +245,38 @@ _FUSED_KINDS = {default_sample_fn: 0, n_step_guided_p_sample: 1, n_step_guided_a
 
 
 # ----------------------------------------------------------------------------- diffusion
-class _LossWeights(nn.Module):
-    """Holds the `loss_fn.weights` buffer so reference checkpoints load strictly (helpers.py:152-157).
-    The losses themselves belong to training and are outside this build."""
+class WeightedLoss(nn.Module):
+    """helpers.py:152-167,193-201: holds the `weights` buffer (so reference checkpoints load strictly).  The
+    arithmetic of the weighted loss runs inside the HIP training step (trebi_amd/training.py, trebi_train_*);
+    calling the module directly is refused -- there is no torch path."""
 
-    def __init__(self, weights):
+    def __init__(self, weights, action_dim, kind):
         super().__init__()
         self.register_buffer('weights', weights)
+        self.action_dim = action_dim
+        self.kind = kind                     # 'l1' | 'l2'
 
-    def forward(self, *a, **k):
-        raise NotImplementedError('training losses are out of scope of the planning hot path')
+    def forward(self, pred, targ):
+        raise RuntimeError('the weighted loss is fused into the HIP training step: use GaussianDiffusion.loss() / '
+                           'trebi_amd.training.TrainStep')
+
+
+class ValueLoss(nn.Module):
+    """helpers.py:169-191,203-211: no buffer (a reference value / cost checkpoint has no `loss_fn.weights` key).
+    Value-net training is outside the hot path (SURVEY 8f covers the denoiser's training step only)."""
+
+    def __init__(self, *args):
+        super().__init__()
+        self.kind = args[-1] if args else 'value_l2'
+
+    def forward(self, pred, targ):
+        raise NotImplementedError('value / cost network training is not part of this build')
+
+
+def _make_loss(loss_type, weights, action_dim):
+    """Losses[loss_type](weights, action_dim), helpers.py:213-218 (KeyError for an unknown type, like the dict)."""
+    table = {'l1': WeightedLoss, 'l2': WeightedLoss, 'value_l1': ValueLoss, 'value_l2': ValueLoss}
+    return table[loss_type](weights, action_dim, loss_type)
 
 
 class GaussianDiffusion(nn.Module):
@@ -292,7 +319,9 @@ class GaussianDiffusion(nn.Module):
             warnings.simplefilter('ignore', DeprecationWarning)       # numpy 2 on Tensor.__array_wrap__
             rb('posterior_mean_coef1', betas * np.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
             rb('posterior_mean_coef2', (1. - alphas_cumprod_prev) * np.sqrt(alphas) / (1. - alphas_cumprod))
-        self.loss_fn = _LossWeights(self.get_loss_weights(action_weight, loss_discount, loss_weights))
+        self.loss_type = loss_type
+        self.loss_fn = _make_loss(loss_type, self.get_loss_weights(action_weight, loss_discount, loss_weights),
+                                  self.action_dim)
         self._samplers = {}
         self._buffers_for = {}
 
@@ -345,8 +374,9 @@ class GaussianDiffusion(nn.Module):
         hu = self.model.net_handle(device)
         hr = rnet.net_handle(device) if rnet is not None else None
         hc = cnet.net_handle(device) if cnet is not None else None
+        gen = lambda n: None if n is None else (id(n), n.generation)
         key = (kind, B, H, tuple(keys), str(device), use_graph, skip_dead_evals,
-               hu.value, hr.value if hr else None, hc.value if hc else None,
+               gen(self.model), gen(rnet), gen(cnet),
                float(kw.get('scale', 0.001)), int(kw.get('t_stopgrad', 0)), int(kw.get('n_guide_steps', 1)),
                bool(kw.get('scale_grad_by_std', True)), bool(kw.get('state_grad_mask', False)),
                float(kw.get('cost_grad_weight', 1.0)), int(kw.get('guide_type', 0)))
@@ -369,8 +399,10 @@ class GaussianDiffusion(nn.Module):
                 _lib.check(_lib.lib().trebi_sampler_create(_ctx(device), hu, hr, hc, C.byref(d), fp(tabs[0]),
                                                            fp(tabs[1]), fp(tabs[2]), B, C.byref(h)))
             if len(self._samplers) >= 8:            # keep a handful of captured loops
-                old = next(iter(self._samplers))
-                _lib.lib().trebi_sampler_destroy(self._samplers.pop(old)['h'])
+                self._drop_sampler(next(iter(self._samplers)))
+            for n in (self.model, rnet, cnet):      # a net frees its samplers before it frees its packed weights
+                if n is not None:
+                    n.add_dependent(self)
             D = self.transition_dim
             T = self.n_timesteps
             self._samplers[key] = dict(
@@ -383,10 +415,22 @@ class GaussianDiffusion(nn.Module):
                 chain=None)
         return self._samplers[key]
 
+    def _drop_sampler(self, key):
+        s = self._samplers.pop(key, None)
+        if s is not None:
+            torch.cuda.synchronize()                # a replay of its graph may still be in flight
+            _lib.lib().trebi_sampler_destroy(s['h'])
+
+    def drop_samplers_of(self, net):
+        """Called by a network right before it frees its packed weights (new parameters were loaded): every captured
+        loop built on that handle holds raw device pointers into them."""
+        for key in [k for k in self._samplers if any(g is not None and g[0] == id(net) for g in k[7:10])]:
+            self._drop_sampler(key)
+
     def __del__(self):
         try:
-            for s in self._samplers.values():
-                _lib.lib().trebi_sampler_destroy(s['h'])
+            for key in list(self._samplers):
+                self._drop_sampler(key)
         except Exception:
             pass
 
@@ -395,6 +439,10 @@ class GaussianDiffusion(nn.Module):
                    use_graph=True, skip_dead_evals=False, profile=False, **sample_kwargs):
         """The fused loop without the final selection: returns (x[B,H,D], values_raw[B], costs[B],
         chain|None) for this rank's candidates.  ShardedPlanner all-gathers values/costs."""
+        if self.predict_epsilon or self.clip_denoised:
+            raise RuntimeError('the fused loop computes x0-parameterised, unclipped steps only (predict_epsilon=False, '
+                               'clip_denoised=False, config/locomotion.py:30,39); use p_sample_loop, which runs such '
+                               'a model step by step through the reference formulas')
         device = self.betas.device
         B, H, D = shape
         if B == 0:                                  # empty batch: nothing to plan (torch would return empty tensors)

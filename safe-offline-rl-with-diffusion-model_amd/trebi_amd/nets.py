@@ -9,6 +9,7 @@ backward-to-input chain in the library.
 """
 import ctypes as C
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -59,6 +60,8 @@ class _HipNet(nn.Module):
         self._handle = None
         self._packed_key = None
         self._ws = {}
+        self.generation = 0                       # bumped whenever the packed weights are rebuilt
+        self._dependents = weakref.WeakSet()      # GaussianDiffusion objects holding captured loops on the handle
 
     # ---- packed weights live in the library; rebuilt when parameters change -----------
     def _desc(self):
@@ -101,10 +104,16 @@ class _HipNet(nn.Module):
                                                        c_numel, n, C.byref(h)))
             self._handle, self._packed_key = h, key
             self._ws = {}
+            self.generation += 1
         return self._handle
+
+    def add_dependent(self, diffusion):
+        self._dependents.add(diffusion)
 
     def _free(self):
         if getattr(self, '_handle', None) is not None:
+            for d in list(getattr(self, '_dependents', ())):      # their plans / graphs point into the packed weights
+                d.drop_samplers_of(self)
             _lib.lib().trebi_net_destroy(self._handle)
             self._handle = None
 
@@ -143,12 +152,19 @@ class _HipNet(nn.Module):
         x = x.contiguous()
         return x, D
 
-    @staticmethod
-    def _time(time, B, device):
+    def _time(self, time, B, device):
+        """[B] int64 timesteps, range-checked on the host: the kernels index per-timestep tables built for
+        t in [0, max_timesteps) (the reference evaluates its embedding for any t; here that is refused loudly)."""
         t = torch.as_tensor(time, device=device)
         if t.dim() == 0:
             t = t.expand(B)
-        return t.to(torch.int64).contiguous()
+        t = t.to(torch.int64).contiguous()
+        if t.numel():
+            lo, hi = (int(v) for v in torch.aminmax(t))              # one read-back; the fused loop never comes here
+            if lo < 0 or hi >= self.max_timesteps:
+                raise RuntimeError(f'timesteps must lie in [0, {self.max_timesteps}) (set_max_timesteps sizes the '
+                                   f'tables); got [{lo}, {hi}]')
+        return t
 
 
 class TemporalUnet(_HipNet):

@@ -22,7 +22,10 @@ def _mk(cls, sd, *a, **k):
 @pytest.mark.parametrize('name,total', [('hopper', 512), ('walker148', 8192), ('halfcheetah', 130),
                                         # position-major tiles (>= 512 candidates) on the other shapes, ragged tails
                                         ('halfcheetah', 601), ('halfcheetah_h4', 1030), ('pendulum_h128', 515),
-                                        ('pendulum', 4100)])
+                                        ('pendulum', 4100),
+                                        # default chain policy: two candidates per workgroup (161-448) and four (449-512),
+                                        # with a last workgroup that is not full
+                                        ('halfcheetah', 201), ('hopper', 447), ('halfcheetah', 450), ('pendulum', 511)])
 def test_copies_of_golden_candidates(name, total):
     from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
     from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn

@@ -168,3 +168,74 @@ def test_sharded_planner_single_rank_equals_loop(setup):
         xs = torch.cat([p[0] for p in parts]); vs = torch.cat([p[1] for p in parts])
         assert rel_err(xs.cpu().numpy(), plan.local_trajectories.cpu().numpy()) < 1e-5
         assert torch.allclose(vs, diff.sample_raw((B, H, D), cond, sample_fn=fn, noise=noise, cost_threshold=thr, **kw)[1], atol=1e-5)
+
+
+def test_epsilon_parameterised_and_clipped_model_follows_the_reference_formulas():
+    """predict_epsilon=True / clip_denoised=True (the constructor defaults, diffusion.py:75) never take the fused
+    x0 loop: sample_raw refuses them, and the per-step route builds x_recon as p_mean_variance does
+    (diffusion.py:153-164,176-181).  Expected values: the same torch expressions on the HIP net's own output
+    (that output is pinned by the golden UNet vectors)."""
+    from diffuser.models import TemporalUnet, GaussianDiffusion
+    from diffuser.models.diffusion import default_sample_fn
+    fx = load_fixture('halfcheetah')
+    sd_u, _, _, um, _ = fixture_weights(fx)
+    H, obs, act, dim, T = int(fx['H']), int(fx['obs']), int(fx['act']), int(fx['dim']), int(fx['T'])
+    D, B = obs + act, int(fx['B'])
+    unet = _mk(TemporalUnet, sd_u, H, D, 0, dim=dim, dim_mults=um)
+    d = GaussianDiffusion(unet, H, obs, act, n_timesteps=T, loss_type='l2', clip_denoised=True,
+                          predict_epsilon=True).cuda()
+    x = torch.from_numpy(fx['net_x']).cuda()
+    cond = {0: torch.from_numpy(fx['cond0']).cuda()[None].repeat(B, 1)}
+    nz = torch.from_numpy(fx['noise'][1]).cuda()
+    with pytest.raises(RuntimeError, match='x0-parameterised'):
+        d.sample_raw((B, H, D), cond, sample_fn=default_sample_fn)
+    for tt in (0, 7, 19):
+        t = torch.full((B,), tt, device='cuda', dtype=torch.long)
+        out, _, _ = default_sample_fn(d, x, cond, t, noise=nz)
+        eps = unet(x, cond, t)
+        xr = (d.sqrt_recip_alphas_cumprod[tt] * x - d.sqrt_recipm1_alphas_cumprod[tt] * eps).clamp(-1., 1.)
+        want = d.posterior_mean_coef1[tt] * xr + d.posterior_mean_coef2[tt] * x
+        if tt != 0:
+            want = want + torch.exp(0.5 * d.posterior_log_variance_clipped[tt]) * nz
+        want[:, 0, act:] = cond[0]
+        assert rel_err(out.cpu().numpy(), want.cpu().numpy()) < 1e-6, tt
+    # the whole loop runs step by step for such a model and stays finite
+    s = d.p_sample_loop((B, H, D), cond, verbose=False, sample_fn=default_sample_fn,
+                        noise=torch.from_numpy(fx['noise']).cuda())
+    assert torch.isfinite(s.trajectories).all()
+
+
+def test_new_weights_after_a_captured_loop_are_used():
+    """load_state_dict after a planning call frees the packed weights the captured loop pointed into: the stale
+    samplers must go with them, and the next call must equal a freshly built model's (use-after-free)."""
+    from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
+    from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
+    from trebi_amd import spec, synth
+    fx = load_fixture('halfcheetah')
+    sd_u, sd_r, sd_c, um, vm = fixture_weights(fx)
+    H, obs, act, dim, T = int(fx['H']), int(fx['obs']), int(fx['act']), int(fx['dim']), int(fx['T'])
+    D, B = obs + act, int(fx['B'])
+    dk = dict(n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False)
+
+    def build(su, sr, sc):
+        diff = GaussianDiffusion(_mk(TemporalUnet, su, H, D, 0, dim=dim, dim_mults=um), H, obs, act, **dk).cuda()
+        g = ValueGuide(ValueDiffusion(_mk(ValueFunction, sr, H, D, 0, dim=dim, dim_mults=vm), H, obs, act, **dk)).cuda()
+        c = ValueGuide(ValueDiffusion(_mk(ValueFunction, sc, H, D, 0, dim=dim, dim_mults=vm), H, obs, act, **dk)).cuda()
+        return diff, g, c
+    new_u = synth.synth_state_dict(spec.unet_param_shapes(H, D, dim, um), 900)
+    new_r = synth.synth_state_dict(spec.value_param_shapes(H, D, dim, vm), 901)
+    cond = {0: torch.from_numpy(fx['cond0']).cuda()[None].repeat(B, 1)}
+    noise = torch.from_numpy(fx['noise']).cuda()
+    thr = torch.full((B,), float(fx['cost_threshold']), device='cuda')
+    kw = fixture_kwargs(fx)
+    run = lambda d, g, c: d.p_sample_loop((B, H, D), cond, verbose=False, sample_fn=fn, noise=noise, guide=g,
+                                          cost_guide=c, cost_threshold=thr, **kw)
+    diff, g, c = build(sd_u, sd_r, sd_c)
+    first = run(diff, g, c)
+    diff.model.load_state_dict({n: torch.from_numpy(v) for n, v in new_u.items()})
+    g.model.model.load_state_dict({n: torch.from_numpy(v) for n, v in new_r.items()})
+    second = run(diff, g, c)
+    fresh = run(*build(new_u, new_r, sd_c))
+    assert torch.equal(second.trajectories, fresh.trajectories) and torch.equal(second.values, fresh.values)
+    assert not torch.equal(first.trajectories, second.trajectories)
+    assert len(diff._samplers) == 1                  # the loop captured on the old weights is gone

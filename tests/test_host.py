@@ -103,3 +103,27 @@ def test_reference_checkpoint_format_loads(tmp_path):
     torch.save({'weights': 1}, bad)
     with pytest.raises(RuntimeError, match='not a reference trainer checkpoint'):
         checkpoint.load_into(dst, bad)
+
+
+def test_loss_type_is_honoured_like_the_reference_losses_table(tmp_path):
+    """helpers.py:213-218: 'l1'/'l2' carry a `weights` buffer, 'value_l1'/'value_l2' (what the reference's value and
+    cost models use, config/locomotion.py:94,137) carry none, anything else is a KeyError.  A reference value
+    checkpoint therefore has no `loss_fn.weights` key and must load with strict=True."""
+    from diffuser.models import ValueFunction, ValueDiffusion, TemporalUnet, GaussianDiffusion
+    from trebi_amd import checkpoint
+    kw = dict(n_timesteps=20, clip_denoised=False, predict_epsilon=False)
+    v = ValueDiffusion(ValueFunction(32, 23, 0), 32, 17, 6, loss_type='value_l2', **kw)
+    assert 'loss_fn.weights' not in v.state_dict()
+    d = GaussianDiffusion(TemporalUnet(32, 23, 0), 32, 17, 6, loss_type='l1', **kw)
+    assert 'loss_fn.weights' in d.state_dict() and d.loss_fn.kind == 'l1'
+    with pytest.raises(KeyError):
+        GaussianDiffusion(TemporalUnet(32, 23, 0), 32, 17, 6, loss_type='huber', **kw)
+    # the reference ValueDiffusion key set (no loss_fn.weights) loads strictly through the checkpoint reader
+    src = ValueDiffusion(ValueFunction(32, 23, 0), 32, 17, 6, loss_type='value_l2', **kw)
+    sd = src.state_dict()
+    assert not any(k.startswith('loss_fn') for k in sd)
+    path = os.path.join(tmp_path, 'state_3.pt')
+    torch.save({'step': 3, 'model': sd, 'ema': sd}, path)
+    assert checkpoint.load_into(v, path) == 3
+    with pytest.raises(RuntimeError):                 # an 'l2' model refuses it: its weights buffer is missing
+        checkpoint.load_into(ValueDiffusion(ValueFunction(32, 23, 0), 32, 17, 6, loss_type='l2', **kw), path)
