@@ -15,7 +15,10 @@
  * Tensor conventions (all float32, contiguous unless a row stride is given):
  *   x, grad, trajectories : [B, horizon, ldx]   (ldx >= transition_dim; the nets read the
  *                                                first transition_dim columns, guides.py:13)
- *   t                     : [B] int64 diffusion timesteps in [0, max_timesteps)
+ *   t                     : [B] int64 diffusion timesteps in [0, max_timesteps).  The library cannot
+ *                           look at device memory without synchronising, so the kernels clamp
+ *                           an out-of-range t to the nearest table row; the host mirror
+ *                           (trebi_amd/nets.py) range-checks and refuses such t loudly.
  *   cond                  : [B, observation_dim] per conditioned horizon index
  */
 #ifndef TREBI_HIP_H
@@ -91,6 +94,20 @@ double trebi_net_flops(const trebi_net* net, int backward);
 size_t trebi_unet_workspace_bytes(const trebi_net* net, int B);
 int trebi_unet_forward(trebi_net* net, const float* x, int ldx, const int64_t* t, float* out,
                        int ldo, int B, void* workspace, size_t workspace_bytes, void* stream);
+
+/* trebi_unet_forward with NO workspace argument and no allocation of any kind: the
+ * activations go to a static per-GPU device array of TREBI_STATIC_SCRATCH_BYTES that the
+ * library's code object carries (every GPU the library runs on holds it until the process
+ * ends).  No counterpart in the reference; it exists for callers that cannot allocate or
+ * size a workspace -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Returns TREBI_WORKSPACE_TOO_SMALL when
+ * trebi_unet_workspace_bytes(net, B) > TREBI_STATIC_SCRATCH_BYTES (about 75
+ * candidates for the halfcheetah H=32 (1,2,4,8) TemporalUnet).  Results are bit-identical to
+ * trebi_unet_forward.  All calls on one GPU share that GPU's array: calls that overlap on
+ * one GPU (two streams, two threads) race; serialise them. */
+#define TREBI_STATIC_SCRATCH_BYTES (32u << 20)
+int trebi_unet_forward_static(trebi_net* net, const float* x, int ldx, const int64_t* t, float* out,
+                              int ldo, int B, void* stream);
 
 /* ValueFunction.forward(x, cond, time)[:, 0] -> y[B]
  * /root/reference/diffuser/models/temporal.py:213-239, guides.py:12-14.

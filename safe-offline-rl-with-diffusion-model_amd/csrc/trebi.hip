@@ -63,6 +63,14 @@ struct trebi_ctx {
   int device;
 };
 
+// Scratch of the one entry point that allocates nothing (trebi_unet_forward_static): a static device array.
+// In host code `g_static_scratch` is only a stand-in for the symbol, never an address a kernel can use: each
+// GPU holds its own copy at its own address, looked up once per device in trebi_ctx_create (that device
+// current) and kept here.  Host code uses g_scratch_ptr[device] only.
+static __device__ __align__(256) unsigned char g_static_scratch[TREBI_STATIC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+static void* g_scratch_ptr[MAX_DEVICES] = {};
+
 // ------------------------------------------------------------------------------------
 // plan data structures
 // ------------------------------------------------------------------------------------
@@ -1475,6 +1483,11 @@ extern "C" int trebi_ctx_create(int device, trebi_ctx** out) {
                 prop.gcnArchName);
   HIPCHK(conv_init_device());
   HIPCHK(chain_init_device());
+  if (device < MAX_DEVICES && !g_scratch_ptr[device]) {
+    void* p = nullptr;
+    HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch)));
+    g_scratch_ptr[device] = p;
+  }
   *out = new trebi_ctx{device};
   return 0;
 }
@@ -1569,6 +1582,28 @@ extern "C" int trebi_unet_forward(trebi_net* net, const float* x, int ldx, const
                 net->desc.transition_dim);
   if (ws_bytes < trebi_unet_workspace_bytes(net, B))
     return fail(TREBI_WORKSPACE_TOO_SMALL, "workspace %zu < %zu bytes", ws_bytes, trebi_unet_workspace_bytes(net, B));
+  Binding b;
+  b.x = x; b.ldx = ldx; b.out = out; b.ldo = ldo; b.t = (const long long*)t; b.ws = (float*)ws;
+  return run_ops(net->fwd, net, b, nullptr, nullptr, nullptr, B, false, (hipStream_t)stream, nullptr);
+}
+
+// The no-allocation variant: same kernels, the workspace is this GPU's static scratch array.  Nothing in the
+// workspace has to start at zero (every buffer is fully written before it is read; trebi_unet_forward runs on
+// uninitialised caller memory too), so the previous call's contents need no clearing.
+extern "C" int trebi_unet_forward_static(trebi_net* net, const float* x, int ldx, const int64_t* t, float* out,
+                                         int ldo, int B, void* stream) {
+  if (!net || !x || !t || !out) return fail(TREBI_BAD_ARG, "null argument");
+  if (net->desc.kind != 0) return fail(TREBI_BAD_ARG, "not a TemporalUnet");
+  if (B < 1 || ldx < net->desc.transition_dim || ldo < net->desc.transition_dim)
+    return fail(TREBI_BAD_SHAPE, "B=%d ldx=%d ldo=%d do not fit transition_dim=%d", B, ldx, ldo,
+                net->desc.transition_dim);
+  const int dev = net->ctx->device;
+  void* ws = dev < MAX_DEVICES ? g_scratch_ptr[dev] : nullptr;
+  if (!ws) return fail(TREBI_HIP_ERROR, "no static scratch on device %d (context not created through trebi_ctx_create)", dev);
+  const size_t need = trebi_unet_workspace_bytes(net, B);
+  if (need > (size_t)TREBI_STATIC_SCRATCH_BYTES)
+    return fail(TREBI_WORKSPACE_TOO_SMALL, "B=%d needs %zu bytes of scratch, the static array holds %u: use "
+                "trebi_unet_forward with a caller workspace", B, need, (unsigned)TREBI_STATIC_SCRATCH_BYTES);
   Binding b;
   b.x = x; b.ldx = ldx; b.out = out; b.ldo = ldo; b.t = (const long long*)t; b.ws = (float*)ws;
   return run_ops(net->fwd, net, b, nullptr, nullptr, nullptr, B, false, (hipStream_t)stream, nullptr);
