@@ -205,6 +205,60 @@ int trebi_sampler_set_profiling(trebi_sampler* s, int enabled);
 int trebi_sampler_get_profile(trebi_sampler* s, double* gemm_us_total, int64_t* gemm_launches,
                               double* gemm_flops_total, double* loop_us_total);
 
+/* ---- the denoiser's training step (BASELINE configs[4]) ----------
+ * GaussianDiffusion.loss / p_losses / q_sample (diffuser/models/diffusion.py:229-261) with
+ * WeightedL2 / WeightedL1 (diffuser/models/helpers.py:152-167,193-201) through a TemporalUnet
+ * (temporal.py:49-151), the full backward that loss.backward() runs there (every weight, bias,
+ * GroupNorm and time-MLP gradient), and Trainer.train's optimiser step: torch.optim.Adam +
+ * the EMA copy (diffuser/utils/training.py:19-35,94-98,104-122).
+ *
+ * Parameters, gradients, Adam moments and the EMA copy are FLAT device buffers of
+ * trebi_trainer_param_count() floats, the TemporalUnet's state_dict tensors back to back in
+ * trebi_net_param_info order (kind 0 descriptor) and in the reference's own layouts; they are
+ * caller-owned (the data-parallel all-reduce is one collective on the flat gradient).  The
+ * trainer owns its workspace (sized for max_batch at create).  create and bind are set-up
+ * calls (they allocate and synchronise); accumulate / step / repack only enqueue. */
+typedef struct trebi_trainer trebi_trainer;
+typedef struct {
+  int horizon, observation_dim, action_dim, n_timesteps;
+  int dim, n_mults, dim_mults[8];
+  int predict_epsilon;  /* target of the loss: 0 x_start (config/locomotion.py:30), 1 the noise */
+  int loss_l1;          /* 0 'l2' (WeightedL2), 1 'l1' (WeightedL1) */
+  int n_cond;           /* conditioned horizon indices (apply_conditioning, helpers.py:142-145) */
+  int cond_index[4];
+} trebi_train_desc;
+
+int trebi_trainer_create(trebi_ctx* ctx, const trebi_train_desc* desc, int max_batch, trebi_trainer** out);
+void trebi_trainer_destroy(trebi_trainer* tr);
+int64_t trebi_trainer_param_count(const trebi_trainer* tr);
+/* Algorithmic FLOPs per sample: forward (backward=0) or dgrad + wgrad (backward=1). */
+double trebi_trainer_flops(const trebi_trainer* tr, int backward);
+
+/* Attach the flat device buffers (exp_avg / exp_avg_sq / ema may be NULL if trebi_trainer_step is
+ * not used / no EMA is kept) and the HOST tables: loss_fn.weights [horizon*transition_dim]
+ * (diffusion.py:122-149), sqrt_alphas_cumprod and sqrt_one_minus_alphas_cumprod [n_timesteps]
+ * (diffusion.py:96-97).  Packs the weights from `params`. */
+int trebi_trainer_bind(trebi_trainer* tr, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                       float* ema, const float* loss_weights, const float* sqrt_alphas_cumprod,
+                       const float* sqrt_one_minus_alphas_cumprod);
+/* After the caller changed `params` itself (load_state_dict): re-pack the kernels' copies. */
+int trebi_trainer_repack(trebi_trainer* tr, void* stream);
+
+/* One micro-batch of Trainer.train (training.py:110-116): x_noisy = q_sample(x_start, t, noise) +
+ * conditioning, x_recon = unet(x_noisy, t) + conditioning, loss = mean(l * weights), then
+ *   grads += grad_scale * d loss / d params        (training.py:115: grad_scale = 1 / gradient_accumulate_every;
+ *                                                    data-parallel: times B_local / B_global before the sum all-reduce)
+ *   loss_out[0] += loss,  loss_out[1] += a0_loss   (dev [2]; the caller zeroes it)
+ * x_start / noise: dev [B, horizon, transition_dim]; t: dev [B] int64; cond[k]: dev [B, observation_dim]. */
+int trebi_trainer_accumulate(trebi_trainer* tr, const float* x_start, const float* const* cond, const int64_t* t,
+                             const float* noise, int B, float grad_scale, float* loss_out, void* stream);
+
+/* optimizer.step(); optimizer.zero_grad(); step_ema() (training.py:118-122, 94-98), then re-pack:
+ * torch.optim.Adam with bias correction for the adam_step-th update (counting from 1);
+ * ema_mode 0: EMA untouched, 1: ema = params (step < step_start_ema), 2: ema = ema*decay + (1-decay)*params. */
+int trebi_trainer_step(trebi_trainer* tr, int64_t adam_step, float lr, float beta1, float beta2, float eps,
+                       int ema_mode, float ema_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

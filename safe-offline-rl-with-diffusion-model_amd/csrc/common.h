@@ -167,4 +167,61 @@ hipError_t launch_feasibility(const float* ry, const float* cy, const float* thr
 hipError_t launch_argsort_desc(const float* v, int n, long long* order, hipStream_t st);
 hipError_t launch_group_argmax(const float* v, int ng, int per, long long* best, hipStream_t st);
 
+
+// ---- training step (train.hip; reference: diffusion.py:229-261, helpers.py:152-167, training.py:19-35,104-122) ----
+// GroupNorm+Mish backward of one Conv1dBlock, standalone (the planning path fuses it into the next conv's prologue;
+// training also needs dY in memory for the weight gradient, and the gamma / beta / bias / time-bias gradients).
+struct GnbP {
+  const float* dA; int ldA;        // dL/d(Mish output) [B*L, ldA] (a column slice of a wider buffer is fine)
+  const float* xhat;               // [B*L, C] saved by the forward
+  const float* stats;              // [B, 8, 2] (mean, rstd)
+  const float* gamma; const float* beta;
+  float* dY;                       // [B*L, C] dL/d(conv output)
+  int B, L, C, gch;
+  float* pcol;                     // [nblk][3][C] per-workgroup partial sums: d gamma, d beta, d bias(conv)
+  float* ptime;                    // [nblk][T][C] per-workgroup partial sums of dA over positions, by timestep; or null
+  const long long* t; int T;
+};
+hipError_t launch_gnb(const GnbP& p, int nblk, hipStream_t st);
+
+// Weight gradient of a convolution as a GEMM over (candidate, position):
+//   dW[cb][ca][tap] = sum_{b, l} A[b, l*stride + tap - pad, ca] * Bm[b, l, cb]
+// (Conv1d: A = layer input, Bm = dY;  ConvTranspose1d: A = dY, Bm = layer input: both give the reference's
+// [dim0][dim1][k] parameter layout).  Workgroup (tile, ks) writes its partial tile to slab[ks][tap][cb][ca].
+struct WgP {
+  const float* A; int ldA, CA, LA;
+  const float* Bm; int ldB, CB, LB;
+  int stride, pad, k;
+  int B, S, spw;                   // S candidates per LDS stage (multiple of 4), spw candidates per workgroup
+  int nwa;                         // waves = 16-channel A tiles per workgroup (TA = 16*nwa)
+  int NB;                          // 16-channel B tiles per workgroup (1, 2 or 4)
+  int SA, SB, ldAs, ldBs;          // LDS strides (floats): per candidate / per row
+  int CA16, CB16, vecA, vecB;
+  float* slab; long slab_stride;   // floats per ks slice = k*CB16*CA16
+};
+hipError_t train_init_device();
+hipError_t launch_wgrad(const WgP& p, int ksplit, hipStream_t st);
+hipError_t launch_wreduce(const float* slab, int ksplit, long slab_stride, int k, int CA, int CB, int CA16, int CB16,
+                          float* grad, hipStream_t st);
+hipError_t launch_colsum(const float* src, int ld, long rows, int C, float* partial /*[nblk][C]*/, int nblk, hipStream_t st);
+struct RJob { const float* src; float* dst; int nblk; int stride; int n; int assign; };   // dst (+)= sum_blk src[blk*stride + i]
+hipError_t launch_reduce_jobs(const RJob* dev_jobs, int njobs, int max_n, hipStream_t st);
+hipError_t launch_add_cols(float* dst, int ldd, const float* src, int lds, long rows, int C, hipStream_t st);
+hipError_t launch_gather(float* dst, const int* map, long n, const float* params, hipStream_t st);
+hipError_t launch_make_map(const float* coded, int* map, long n, hipStream_t st);
+hipError_t launch_qsample(const StepP& s, const float* x0, const float* noise, const long long* t, const float* sa,
+                          const float* sb, float* out, int B, hipStream_t st);
+// weighted loss (helpers.py:159-167) + its gradient wrt the net output; loss_out[0] += weighted loss, [1] += a0 loss
+hipError_t launch_loss(const StepP& s, const float* pred, const float* targ, const float* w /*[H,D]*/, int l1,
+                       float inv_count, float inv_a0, float gscale, float* dout, float* loss_out, int B, hipStream_t st);
+hipError_t launch_adam_ema(float* p, float* g, float* m, float* v, float* ema, long n, float b1, float b2, float step_size,
+                           float inv_bc2_sqrt, float eps, int ema_mode, float ema_decay, hipStream_t st);
+hipError_t launch_time_embed_train(const float* w1, const float* b1, const float* w2, const float* b2, int dim, int T,
+                                   float* e /*[T,dim]*/, float* a1 /*[T,4dim]*/, float* temb /*[T,dim]*/, hipStream_t st);
+struct TBJob { const float* G; const float* Wt; float* gW; float* gb; float* DT; int C; int pad; };
+hipError_t launch_time_block_bwd(const TBJob* dev_jobs, int njobs, const float* temb, int dim, int T, hipStream_t st);
+hipError_t launch_time_mlp_bwd(const float* DT, int njobs, const float* e, const float* a1, const float* temb,
+                               const float* W3, int dim, int T, float* gW1, float* gb1, float* gW3, float* gb3,
+                               hipStream_t st);
+
 }  // namespace trebi

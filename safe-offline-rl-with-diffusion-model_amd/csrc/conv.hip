@@ -682,7 +682,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
         if (sy) {
           unsigned so = ((unsigned)b0 * Lout + row) * (unsigned)N + n0 + col;
           gst4(sy + so, xh);
-          gst4(sg + so, dm * ga);
+          if (sg) gst4(sg + so, dm * ga);          // training keeps xhat only (train.hip recomputes mish')
         }
         finish(m, s, row, col);
       }

@@ -74,6 +74,17 @@ struct FastDiv {
 // fields with an s_load + s_waitcnt in front of every use (hundreds of stall cycles per use).
 #define PIN(x) asm volatile("" : "+s"(x))
 
+// apply_conditioning (helpers.py:142-145): is element (h, d) of candidate b overwritten by a condition?
+__device__ __forceinline__ bool conditioned(const StepP& s, int h, int d, int b, float* val) {
+  if (d < s.act || d >= s.act + s.obs) return false;
+  for (int k = 0; k < s.n_cond; ++k)
+    if (s.cond_index[k] == h) {
+      *val = s.cond[k][(size_t)b * s.obs + (d - s.act)];
+      return true;
+    }
+  return false;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));

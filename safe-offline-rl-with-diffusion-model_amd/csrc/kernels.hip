@@ -123,15 +123,6 @@ hipError_t launch_time_linear(const float* w, int ldw, int col0, const float* b,
 // ----------------------------------------------------------------------------------
 // Elementwise steps of the sample functions
 // ----------------------------------------------------------------------------------
-__device__ __forceinline__ bool conditioned(const StepP& s, int h, int d, int b, float* val) {
-  if (d < s.act || d >= s.act + s.obs) return false;
-  for (int k = 0; k < s.n_cond; ++k)
-    if (s.cond_index[k] == h) {
-      *val = s.cond[k][(size_t)b * s.obs + (d - s.act)];
-      return true;
-    }
-  return false;
-}
 
 // functions.py:95-119 (constrained), :21-29 (reward-only)
 __global__ void guide_update_kernel(StepP s, float* x, const float* rg, const float* cg, const float* cy,

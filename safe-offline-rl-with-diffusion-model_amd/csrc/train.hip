@@ -1,0 +1,568 @@
+// train.hip -- gfx950 kernels of the TemporalUnet TRAINING step (BASELINE configs[4]).
+//
+// Reference: GaussianDiffusion.q_sample / p_losses / loss (diffuser/models/diffusion.py:229-261), WeightedL2 / L1
+// (diffuser/models/helpers.py:152-167,193-201), what torch.autograd computes for Conv1d / ConvTranspose1d /
+// GroupNorm / Mish / Linear on the way back through TemporalUnet (temporal.py:18-46,120-151), torch.optim.Adam and
+// the trainer's EMA rule (diffuser/utils/training.py:19-35,94-98,104-122).
+//
+// The forward and the input-gradient (dgrad) convolutions are conv_gemm_kernel (conv.hip) -- the same kernels the
+// planning path runs.  What is new here:
+//   wgrad_kernel      weight gradient as a GEMM with K = (candidate, position) on v_mfma_f32_16x16x4_f32:
+//                     dW[cb][ca][tap] = sum A[b, l*stride+tap-pad, ca] * Bm[b, l, cb].  The four k-slots of one
+//                     MFMA are the SAME position of four candidates, so a (position, tap) pair that falls on zero
+//                     padding is skipped as a whole and no halo is staged.  K is split over workgroups; every
+//                     workgroup stores its partial tile to a slab and wreduce_kernel sums the slabs into the
+//                     gradient in the reference's [cb][ca][tap] layout (plain stores + a sum pass instead of float
+//                     atomics: bitwise reproducible and, per MI355X_MICROARCH.md "Global float atomics", faster).
+//   gnb_kernel        GroupNorm+Mish backward of a Conv1dBlock: dY, and per-workgroup partial sums of the gamma /
+//                     beta / conv-bias gradients and of the time-bias gradient scattered by timestep.
+//   the elementwise ends: q_sample + conditioning, weighted loss + its gradient, Adam + EMA, the weight re-pack
+//   (gather through an index map), the small time-MLP backward.
+#include "device_util.h"
+
+#include <algorithm>
+
+namespace trebi {
+
+// =====================================================================================================
+// q_sample + apply_conditioning   (diffusion.py:229-238, 243-244)
+// =====================================================================================================
+__global__ void qsample_kernel(StepP s, const float* x0, const float* noise, const long long* t, const float* sa,
+                               const float* sb, float* out, int B) {
+  const size_t per = (size_t)s.H * s.D, total = (size_t)B * per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per), r = (int)(i - (size_t)b * per), h = r / s.D, d = r - h * s.D;
+    long long tt = t[b];
+    const int ti = tt < 0 ? 0 : (tt >= s.T ? s.T - 1 : (int)tt);
+    float v = sa[ti] * x0[i] + sb[ti] * noise[i];
+    float cv;
+    if (conditioned(s, h, d, b, &cv)) v = cv;
+    out[i] = v;
+  }
+}
+hipError_t launch_qsample(const StepP& s, const float* x0, const float* noise, const long long* t, const float* sa,
+                          const float* sb, float* out, int B, hipStream_t st) {
+  const size_t total = (size_t)B * s.H * s.D;
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(qsample_kernel, dim3(blocks), dim3(256), 0, st, s, x0, noise, t, sa, sb, out, B);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// weighted loss and its gradient   (diffusion.py:246-254, helpers.py:159-167)
+//   x_recon = apply_conditioning(net output);  l = (x_recon - targ)^2 (or |.|);  loss = mean(l * w)
+//   a0_loss = mean(l[:, 0, :act] / w[0, :act]);  d loss / d(net output) = 0 where the output was overwritten
+// =====================================================================================================
+__global__ __launch_bounds__(256) void loss_kernel(StepP s, const float* pred, const float* targ, const float* w, int l1,
+                                                   float inv_count, float inv_a0, float gscale, float* dout,
+                                                   float* loss_out, int B) {
+  const size_t per = (size_t)s.H * s.D, total = (size_t)B * per;
+  float ls = 0.f, as = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per), r = (int)(i - (size_t)b * per), h = r / s.D, d = r - h * s.D;
+    float p = pred[i], cv;
+    const bool over = conditioned(s, h, d, b, &cv);
+    if (over) p = cv;
+    const float df = p - targ[i], wt = w[r];
+    const float l = l1 ? fabsf(df) : df * df;
+    ls += l * wt;
+    if (h == 0 && d < s.act) as += l / wt;
+    const float g = l1 ? (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) : 2.f * df;
+    dout[i] = over ? 0.f : g * wt * gscale;
+  }
+  __shared__ float red[2][4];
+  ls = wave_sum(ls);
+  as = wave_sum(as);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ls; red[1][threadIdx.x >> 6] = as; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(loss_out, (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv_count);
+    atomicAdd(loss_out + 1, (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv_a0);
+  }
+}
+hipError_t launch_loss(const StepP& s, const float* pred, const float* targ, const float* w, int l1, float inv_count,
+                       float inv_a0, float gscale, float* dout, float* loss_out, int B, hipStream_t st) {
+  const size_t total = (size_t)B * s.H * s.D;
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 512);
+  hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(256), 0, st, s, pred, targ, w, l1, inv_count, inv_a0, gscale, dout,
+                     loss_out, B);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// GroupNorm + Mish backward of a Conv1dBlock (helpers.py:46-63)
+//   z = gamma*xhat + beta;  dz = dA * mish'(z);  d gamma = sum dz*xhat;  d beta = sum dz
+//   dxhat = dz*gamma;  dY = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat));  d bias = sum dY
+//   time bias (temporal.py:44): d tb[b, c] = sum_l dA[b, l, c], scattered into row t[b] of a [T, C] table
+// A team of 16 lanes owns one (candidate, group): both passes stay inside the team (DPP reductions).
+// =====================================================================================================
+template <int R>
+__device__ __forceinline__ float ror_add(float v) {      // v + (v rotated right by R inside its row of 16 lanes)
+  return v + dpp_f<0x120 + R>(v);
+}
+// sum over the lanes of a 16-lane row that share (lane % g4); g4 a power of two <= 16
+__device__ __forceinline__ float stride_sum(float v, int g4) {
+  if (g4 <= 8) v = ror_add<8>(v);
+  if (g4 <= 4) v = ror_add<4>(v);
+  if (g4 <= 2) v = ror_add<2>(v);
+  if (g4 <= 1) v = ror_add<1>(v);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gnb_kernel(GnbP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = p.C, T = p.T;
+  float* colacc = sm;                       // [3][C]
+  float* ttab = sm + 3 * C;                 // [T][C]
+  const int nt = 3 * C + (p.ptime ? T * C : 0);
+  for (int i = threadIdx.x; i < nt; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
+  const int gch = p.gch, g4 = gch >> 2, L = p.L, cnt4 = L * g4;
+  const float icnt = 1.f / (float)(cnt4 * 4);
+  const int ninst = p.B * GN_GROUPS;
+  const int c4 = tl & (g4 - 1);             // the float4 column of this lane inside the group (16 % g4 == 0)
+  for (int inst = blockIdx.x * 16 + team; inst < ninst; inst += gridDim.x * 16) {
+    const int b = inst >> 3, gi = inst & 7;
+    const int c = gi * gch + 4 * c4;
+    const float rstd = gld(p.stats + 2 * inst + 1);
+    const f32x4 ga = gld4(p.gamma + c), be = gld4(p.beta + c);
+    const size_t row0 = (size_t)b * L;
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 dga = {0.f, 0.f, 0.f, 0.f}, dbe = dga, dtb = dga, dbi = dga;
+    for (int e = tl; e < cnt4; e += 16) {
+      const int li = e / g4;
+      const f32x4 da = gld4(p.dA + (row0 + li) * (size_t)p.ldA + c);
+      const f32x4 xh = gld4(p.xhat + (row0 + li) * (size_t)C + c);
+      f32x4 dz;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dz[q] = da[q] * mish_grad_f(xh[q] * ga[q] + be[q]);
+      const f32x4 dx = dz * ga;
+      s1 += hsum(dx);
+      s2 += hsum(dx * xh);
+      dga += dz * xh;
+      dbe += dz;
+      dtb += da;
+    }
+    // team sums (16 lanes = one DPP row)
+    s1 += dpp_f<0xB1>(s1); s1 += dpp_f<0x4E>(s1); s1 += dpp_f<0x141>(s1); s1 += dpp_f<0x140>(s1);
+    s2 += dpp_f<0xB1>(s2); s2 += dpp_f<0x4E>(s2); s2 += dpp_f<0x141>(s2); s2 += dpp_f<0x140>(s2);
+    const float m1 = s1 * icnt, m2 = s2 * icnt;
+    for (int e = tl; e < cnt4; e += 16) {
+      const int li = e / g4;
+      const f32x4 da = gld4(p.dA + (row0 + li) * (size_t)p.ldA + c);
+      const f32x4 xh = gld4(p.xhat + (row0 + li) * (size_t)C + c);
+      f32x4 dy;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float dx = da[q] * mish_grad_f(xh[q] * ga[q] + be[q]) * ga[q];
+        dy[q] = (dx - m1 - xh[q] * m2) * rstd;
+      }
+      dbi += dy;
+      gst4(p.dY + (row0 + li) * (size_t)C + c, dy);
+    }
+    // column sums over the positions of this candidate: lanes with the same c4 hold different positions
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dga[q] = stride_sum(dga[q], g4);
+      dbe[q] = stride_sum(dbe[q], g4);
+      dbi[q] = stride_sum(dbi[q], g4);
+      dtb[q] = stride_sum(dtb[q], g4);
+    }
+    if (tl < g4) {
+      long long tt = 0;
+      if (p.ptime) {
+        tt = gldll(p.t + b);
+        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        atomicAdd(&colacc[c + q], dga[q]);
+        atomicAdd(&colacc[C + c + q], dbe[q]);
+        atomicAdd(&colacc[2 * C + c + q], dbi[q]);
+        if (p.ptime) atomicAdd(&ttab[(int)tt * C + c + q], dtb[q]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256) gst(p.pcol + (size_t)blockIdx.x * 3 * C + i, colacc[i]);
+  if (p.ptime)
+    for (int i = threadIdx.x; i < T * C; i += 256) gst(p.ptime + (size_t)blockIdx.x * T * C + i, ttab[i]);
+}
+hipError_t launch_gnb(const GnbP& p, int nblk, hipStream_t st) {
+  const size_t lds = (size_t)(3 * p.C + (p.ptime ? p.T * p.C : 0)) * sizeof(float);
+  hipLaunchKernelGGL(gnb_kernel, dim3(nblk), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// column sums of a [rows, ld] tensor (bias gradients of the convolutions that have no GroupNorm behind them)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void colsum_kernel(const float* src, int ld, long rows, int C, float* partial) {
+  __shared__ float red[256];
+  int CW = 1;
+  while (CW < C && CW < 256) CW <<= 1;
+  const int c = threadIdx.x % CW, rl = threadIdx.x / CW, nrl = 256 / CW;
+  const long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long r0 = (long)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  for (int cb = 0; cb < C; cb += CW) {           // (C <= 256 everywhere on this path: one trip); uniform trip count
+    const int cc = cb + c;
+    float a = 0.f;
+    if (cc < C)
+      for (long r = r0 + rl; r < r1; r += nrl) a += gld(src + r * ld + cc);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (rl == 0 && cc < C) {
+      for (int k = 1; k < nrl; ++k) a += red[k * CW + c];
+      gst(partial + (size_t)blockIdx.x * C + cc, a);
+    }
+    __syncthreads();
+  }
+}
+hipError_t launch_colsum(const float* src, int ld, long rows, int C, float* partial, int nblk, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, st, src, ld, rows, C, partial);
+  return hipGetLastError();
+}
+
+// dst[i] (+)= sum_blk src[blk*stride + i]: all per-workgroup partial tables of one backward pass in ONE launch
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(const RJob* jobs) {
+  const RJob j = jobs[blockIdx.y];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < j.n; i += gridDim.x * 256) {
+    float a = 0.f;
+    for (int b = 0; b < j.nblk; ++b) a += gld(j.src + (size_t)b * j.stride + i);
+    j.dst[i] = j.assign ? a : j.dst[i] + a;
+  }
+}
+hipError_t launch_reduce_jobs(const RJob* dev_jobs, int njobs, int max_n, hipStream_t st) {
+  int bx = (max_n + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(reduce_jobs_kernel, dim3(bx, njobs), dim3(256), 0, st, dev_jobs);
+  return hipGetLastError();
+}
+
+// dst[r, c] += src[r, c] (skip-connection gradients meeting the main path, temporal.py:142)
+__global__ void add_cols_kernel(float* dst, int ldd, const float* src, int lds, long rows, int C4) {
+  const long total = rows * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C4;
+    const int c = 4 * (int)(i - r * C4);
+    gst4(dst + r * ldd + c, gld4(dst + r * ldd + c) + gld4(src + r * lds + c));
+  }
+}
+hipError_t launch_add_cols(float* dst, int ldd, const float* src, int lds, long rows, int C, hipStream_t st) {
+  const long total = rows * (C / 4);
+  int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(add_cols_kernel, dim3(blocks), dim3(256), 0, st, dst, ldd, src, lds, rows, C / 4);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// weight gradient GEMM
+// =====================================================================================================
+template <int NB>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, lr = lane & 15;
+  const int nthr = 64 * p.nwa, TA = 16 * p.nwa, TB = 16 * NB;
+  const int nta = p.CA16 / TA;                           // A tiles
+  const int ta = blockIdx.x % nta, tb = blockIdx.x / nta;
+  const int ca0 = ta * TA, cb0 = tb * TB;
+  const int S = p.S, LA = p.LA, LB = p.LB, ldAs = p.ldAs, ldBs = p.ldBs, SA = p.SA, SB = p.SB;
+  float* As = sm;
+  float* Bs = sm + S * SA;
+  const int s_begin = blockIdx.y * p.spw;
+  const int s_end = s_begin + p.spw < p.B ? s_begin + p.spw : p.B;
+  f32x4 acc[5][NB];
+#pragma unroll
+  for (int tp = 0; tp < 5; ++tp)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[tp][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int ta4 = TA / 4, tb4 = TB / 4;
+  const int stride = p.stride, pad = p.pad, k = p.k;
+  for (int s0 = s_begin; s0 < s_end; s0 += S) {
+    // ---- stage S candidates: A rows [s][pos][TA], B rows [s][l][TB]; zero beyond the batch / the channels ----
+    {
+      const int nA = S * LA * ta4;
+      for (int i = tid; i < nA; i += nthr) {
+        const int row = i / ta4, c4 = i - row * ta4;
+        const int s = row / LA, pos = row - s * LA;
+        const int ch = ca0 + 4 * c4;
+        const int left = (s0 + s < s_end) ? p.CA - ch : 0;
+        const float* sp = p.A + ((size_t)(s0 + s) * LA + pos) * p.ldA + ch;
+        const f32x4 v = p.vecA ? load4<true>(sp, left) : load4<false>(sp, left);
+        *(f32x4*)&As[s * SA + pos * ldAs + 4 * c4] = v;
+      }
+      const int nB = S * LB * tb4;
+      for (int i = tid; i < nB; i += nthr) {
+        const int row = i / tb4, c4 = i - row * tb4;
+        const int s = row / LB, l = row - s * LB;
+        const int ch = cb0 + 4 * c4;
+        const int left = (s0 + s < s_end) ? p.CB - ch : 0;
+        const float* sp = p.Bm + ((size_t)(s0 + s) * LB + l) * p.ldB + ch;
+        const f32x4 v = p.vecB ? load4<true>(sp, left) : load4<false>(sp, left);
+        *(f32x4*)&Bs[s * SB + l * ldBs + 4 * c4] = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: k-slot g of an instruction = candidate 4*sq + g, all four at the same position ----
+    const float* aw = As + g * SA + wave * 16 + lr;
+    const float* bw = Bs + g * SB + lr;
+    for (int sq = 0; sq < S / 4; ++sq) {
+      const float* a_s = aw + sq * 4 * SA;
+      const float* b_s = bw + sq * 4 * SB;
+      for (int l = 0; l < LB; ++l) {
+        float bf[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bf[nb] = b_s[l * ldBs + nb * 16];
+        const int pos0 = l * stride - pad;
+#pragma unroll
+        for (int tp = 0; tp < 5; ++tp) {
+          const int pos = pos0 + tp;
+          if (tp < k && (unsigned)pos < (unsigned)LA) {           // wave-uniform: zero padding is skipped whole
+            const float a = a_s[pos * ldAs];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[tp][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb], acc[tp][nb], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- partial tile -> slab[ks][tap][cb][ca]: D[i][j]: lane holds rows i = 4g..4g+3 (ca), column j = lr (cb) ----
+  float* out = p.slab + (size_t)blockIdx.y * p.slab_stride;
+#pragma unroll
+  for (int tp = 0; tp < 5; ++tp)
+    if (tp < k) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int cb = cb0 + nb * 16 + lr, ca = ca0 + wave * 16 + 4 * g;
+        gst4(out + ((size_t)tp * p.CB16 + cb) * p.CA16 + ca, acc[tp][nb]);
+      }
+    }
+}
+
+hipError_t train_init_device() {
+  hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return e;
+}
+
+hipError_t launch_wgrad(const WgP& p, int ksplit, hipStream_t st) {
+  if (p.k > 5 || p.nwa < 1 || p.nwa > 4 || p.S % 4 || p.CA16 % (16 * p.nwa) || p.CB16 % (16 * p.NB))
+    return hipErrorInvalidValue;
+  const size_t lds = (size_t)p.S * (p.SA + p.SB) * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  dim3 grid((p.CA16 / (16 * p.nwa)) * (p.CB16 / (16 * p.NB)), ksplit), block(64 * p.nwa);
+  switch (p.NB) {
+    case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, block, lds, st, p); break;
+    case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, block, lds, st, p); break;
+    case 4: hipLaunchKernelGGL(wgrad_kernel<4>, grid, block, lds, st, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// grad[(cb*CA + ca)*k + tap] += sum_ks slab[ks][tap][cb][ca]
+__global__ __launch_bounds__(256) void wreduce_kernel(const float* slab, int ksplit, long slab_stride, int k, int CA,
+                                                      int CB, int CA16, int CB16, float* grad) {
+  const long n = (long)k * CB16 * CA16;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int ca = (int)(i % CA16);
+    const long r = i / CA16;
+    const int cb = (int)(r % CB16), tp = (int)(r / CB16);
+    if (ca >= CA || cb >= CB) continue;
+    float a = 0.f;
+    for (int s = 0; s < ksplit; ++s) a += gld(slab + (size_t)s * slab_stride + i);
+    grad[((size_t)cb * CA + ca) * k + tp] += a;
+  }
+}
+hipError_t launch_wreduce(const float* slab, int ksplit, long slab_stride, int k, int CA, int CB, int CA16, int CB16,
+                          float* grad, hipStream_t st) {
+  const long n = (long)k * CB16 * CA16;
+  int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(wreduce_kernel, dim3(blocks), dim3(256), 0, st, slab, ksplit, slab_stride, k, CA, CB, CA16, CB16, grad);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// weight re-pack: the kernels' packed layouts are pure permutations (+ zero fill) of the reference tensors, so a
+// map from packed position to flat parameter index (built once, see trebi.hip) turns the re-pack after every
+// optimiser step into one gather
+// =====================================================================================================
+__global__ void gather_kernel(float* dst, const int* map, long n, const float* params) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int m = map[i];
+    if (m >= 0) dst[i] = params[m];
+  }
+}
+hipError_t launch_gather(float* dst, const int* map, long n, const float* params, hipStream_t st) {
+  int blocks = (int)std::min<long>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, dst, map, n, params);
+  return hipGetLastError();
+}
+// coded[i] = 1 + flat parameter index as a float (exact below 2^24), 0 = structural zero
+__global__ void make_map_kernel(const float* coded, int* map, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    map[i] = (int)coded[i] - 1;
+}
+hipError_t launch_make_map(const float* coded, int* map, long n, hipStream_t st) {
+  int blocks = (int)std::min<long>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(make_map_kernel, dim3(blocks), dim3(256), 0, st, coded, map, n);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// torch.optim.Adam (bias-corrected, eps added after the corrected sqrt) + the trainer's EMA copy + zero_grad
+//   ema_mode 0: leave, 1: ema = p (training.py:95-97), 2: ema = ema*decay + (1-decay)*p (training.py:32-35)
+// =====================================================================================================
+__global__ void adam_ema_kernel(float* p, float* g, float* m, float* v, float* ema, long n, float b1, float b2,
+                                float step_size, float inv_bc2_sqrt, float eps, int ema_mode, float decay) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    const float pi = p[i] - step_size * (mi / denom);
+    p[i] = pi;
+    g[i] = 0.f;
+    if (ema_mode == 1) ema[i] = pi;
+    else if (ema_mode == 2) ema[i] = ema[i] * decay + (1.f - decay) * pi;
+  }
+}
+hipError_t launch_adam_ema(float* p, float* g, float* m, float* v, float* ema, long n, float b1, float b2, float step_size,
+                           float inv_bc2_sqrt, float eps, int ema_mode, float ema_decay, hipStream_t st) {
+  int blocks = (int)std::min<long>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, ema, n, b1, b2, step_size, inv_bc2_sqrt,
+                     eps, ema_mode, ema_decay);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// time embedding: forward tables that keep what the backward needs, and the backward
+//   e = SinusoidalPosEmb(t);  a1 = W1 e + b1;  temb = W3 mish(a1) + b3      (temporal.py:70-75, helpers.py:21-28)
+//   block i: tb_i = Wt_i mish(temb) + bt_i                                    (temporal.py:28-32)
+// t only takes the T integer values, so every gradient of this path is a [T, .] table problem.
+// =====================================================================================================
+__global__ void time_embed_train_kernel(const float* w1, const float* b1, const float* w2, const float* b2, int dim,
+                                        int T, float* e_out, float* a1_out, float* temb) {
+  extern __shared__ float sm[];
+  float* e = sm;             // [dim]
+  float* h = sm + dim;       // [4*dim]
+  const int t = blockIdx.x, half = dim / 2;
+  const float sc = logf(10000.f) / (float)(half - 1);
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    float f = expf((float)i * -sc), a = (float)t * f;
+    e[i] = sinf(a);
+    e[half + i] = cosf(a);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < dim; i += blockDim.x) e_out[(size_t)t * dim + i] = e[i];
+  for (int j = threadIdx.x; j < 4 * dim; j += blockDim.x) {
+    float a = b1[j];
+    for (int i = 0; i < dim; ++i) a = fmaf(w1[j * dim + i], e[i], a);
+    a1_out[(size_t)t * 4 * dim + j] = a;
+    h[j] = mish_f(a);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < dim; j += blockDim.x) {
+    float a = b2[j];
+    for (int i = 0; i < 4 * dim; ++i) a = fmaf(w2[j * 4 * dim + i], h[i], a);
+    temb[(size_t)t * dim + j] = a;
+  }
+}
+hipError_t launch_time_embed_train(const float* w1, const float* b1, const float* w2, const float* b2, int dim, int T,
+                                   float* e, float* a1, float* temb, hipStream_t st) {
+  hipLaunchKernelGGL(time_embed_train_kernel, dim3(T), dim3(128), (size_t)5 * dim * sizeof(float), st, w1, b1, w2, b2, dim,
+                     T, e, a1, temb);
+  return hipGetLastError();
+}
+
+// per block: gW[c][k] += sum_t G[t][c] * mish(temb[t][k]);  gb[c] += sum_t G[t][c];
+//            DT[t][k] = sum_c G[t][c] * Wt[c][k]      (the block's contribution to d mish(temb))
+__global__ __launch_bounds__(256) void time_block_bwd_kernel(const TBJob* jobs, const float* temb, int dim, int T) {
+  const TBJob j = jobs[blockIdx.x];
+  const int C = j.C;
+  for (int i = threadIdx.x; i < C * dim; i += 256) {
+    const int c = i / dim, k = i - c * dim;
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a = fmaf(j.G[t * C + c], mish_f(temb[t * dim + k]), a);
+    j.gW[i] += a;
+  }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a += j.G[t * C + c];
+    j.gb[c] += a;
+  }
+  for (int i = threadIdx.x; i < T * dim; i += 256) {
+    const int t = i / dim, k = i - t * dim;
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a = fmaf(j.G[t * C + c], j.Wt[c * dim + k], a);
+    j.DT[i] = a;
+  }
+}
+hipError_t launch_time_block_bwd(const TBJob* dev_jobs, int njobs, const float* temb, int dim, int T, hipStream_t st) {
+  hipLaunchKernelGGL(time_block_bwd_kernel, dim3(njobs), dim3(256), 0, st, dev_jobs, temb, dim, T);
+  return hipGetLastError();
+}
+
+// d temb = mish'(temb) * sum_blocks DT;  then the two Linears of time_mlp backwards (one workgroup: it is tiny)
+__global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const float* DT, int njobs, const float* e, const float* a1,
+                                                           const float* temb, const float* W3, int dim, int T,
+                                                           float* gW1, float* gb1, float* gW3, float* gb3) {
+  extern __shared__ float sm[];
+  float* dte = sm;                  // [T][dim]
+  float* da1 = sm + T * dim;        // [T][4dim]
+  const int d4 = 4 * dim;
+  for (int i = threadIdx.x; i < T * dim; i += 256) {
+    float a = 0.f;
+    for (int j = 0; j < njobs; ++j) a += DT[(size_t)j * T * dim + i];
+    dte[i] = a * mish_grad_f(temb[i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < dim * d4; i += 256) {        // gW3[j][i2] = sum_t dte[t][j] * mish(a1[t][i2])
+    const int jj = i / d4, i2 = i - jj * d4;
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a = fmaf(dte[t * dim + jj], mish_f(a1[t * d4 + i2]), a);
+    gW3[i] += a;
+  }
+  for (int jj = threadIdx.x; jj < dim; jj += 256) {
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a += dte[t * dim + jj];
+    gb3[jj] += a;
+  }
+  for (int i = threadIdx.x; i < T * d4; i += 256) {          // da1[t][i2] = mish'(a1) * sum_j dte[t][j] W3[j][i2]
+    const int t = i / d4, i2 = i - t * d4;
+    float a = 0.f;
+    for (int jj = 0; jj < dim; ++jj) a = fmaf(dte[t * dim + jj], W3[jj * d4 + i2], a);
+    da1[i] = a * mish_grad_f(a1[i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < d4 * dim; i += 256) {        // gW1[i2][k] = sum_t da1[t][i2] * e[t][k]
+    const int i2 = i / dim, k = i - i2 * dim;
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a = fmaf(da1[t * d4 + i2], e[t * dim + k], a);
+    gW1[i] += a;
+  }
+  for (int i2 = threadIdx.x; i2 < d4; i2 += 256) {
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a += da1[t * d4 + i2];
+    gb1[i2] += a;
+  }
+}
+hipError_t launch_time_mlp_bwd(const float* DT, int njobs, const float* e, const float* a1, const float* temb,
+                               const float* W3, int dim, int T, float* gW1, float* gb1, float* gW3, float* gb3,
+                               hipStream_t st) {
+  const size_t lds = (size_t)T * 5 * dim * sizeof(float);
+  hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(1), dim3(256), lds, st, DT, njobs, e, a1, temb, W3, dim, T, gW1, gb1, gW3,
+                     gb3);
+  return hipGetLastError();
+}
+
+}  // namespace trebi

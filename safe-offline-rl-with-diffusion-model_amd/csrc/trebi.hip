@@ -112,6 +112,47 @@ struct Op {
   int v_buf = NONE, dv_buf = NONE;
 };
 
+// What the training backward needs to know about the forward graph of a TemporalUnet (filled by build_unet).
+struct RBInfo {                      // one ResidualTemporalBlock
+  std::string prefix;
+  int cin = 0, cout = 0, L = 0;
+  bool has_res = false;
+  BufRef src, dst;                   // block input / output
+  int a0 = NONE;                     // blocks.0 output (+ time bias) = blocks.1 input
+  int y0 = NONE, st0 = NONE, y1 = NONE, st1 = NONE;   // saved xhat / (mean, rstd) of the two Conv1dBlocks
+  GnW gn0, gn1;
+};
+struct ResampleInfo { std::string name; int C = 0, Lin = 0; BufRef src, dst; };
+struct UnetRec {
+  std::vector<RBInfo> down0, down1, up0, up1;
+  std::vector<ResampleInfo> downs, ups;            // name empty: no resampling conv at that level
+  std::vector<int> catC;                           // per up step: channels of the left (main path) half of the concat
+  RBInfo mid1, mid2;
+  BufRef final_src;
+  int final_fb = NONE, final_y = NONE, final_st = NONE, final_L = 0;
+  GnW final_gn;
+};
+
+// One step of the training backward (trainer.inl).
+struct TOp {
+  int kind = 0;                      // 0 input-gradient conv, 1 GroupNorm+Mish backward, 2 weight gradient, 3 column sum, 4 add
+  std::string name;
+  Op conv;
+  // kind 1
+  BufRef dA;
+  int xhat = NONE, stats = NONE, dY = NONE, L = 0, C = 0;
+  GnW gn;
+  long off_gamma = -1, off_beta = -1, off_bias = -1;
+  int time_blk = -1;                 // index of the ResidualTemporalBlock whose time bias this gradient feeds, or -1
+  // kind 2:  dW[cb][ca][tap] = sum A[b, l*stride + tap - pad, ca] * Bm[b, l, cb]
+  BufRef A, Bm;
+  int CA = 0, LA = 0, CB = 0, LB = 0, stride = 1, pad = 0, k = 1;
+  long off_w = -1;
+  // kind 3: off_bias += column sums of src [B*L, C];  kind 4: dst2 += src
+  BufRef src, dst2;
+  double flops = 0;                  // algorithmic, per sample
+};
+
 struct Binding {
   const float* x = nullptr;
   int ldx = 0;
@@ -141,6 +182,19 @@ struct trebi_net {
   float head_b2 = 0.f;
   int fc = 0, hd = 0;
   double flops_fwd = 0, flops_bwd = 0;
+  // training (trainer.inl): every uploaded region (so that it can be re-packed from the flat parameters), the
+  // time-table jobs to re-run after a re-pack, the forward graph record and the backward step list
+  bool train = false;
+  std::vector<size_t> alloc_bytes;
+  std::vector<std::pair<float*, size_t>> uploads;
+  struct TimeJob { int kind; const float *w, *b, *w2, *b2; int ldw, col0, N, mish; float* out; };
+  std::vector<TimeJob> time_jobs;
+  float *tt_e = nullptr, *tt_a1 = nullptr, *tt_temb = nullptr;
+  UnetRec rec;
+  std::vector<TOp> tops;
+  std::vector<std::string> time_blocks;            // prefixes of the blocks with a time_mlp, in backward order of use
+  int buf_dy = NONE, buf_colscratch = NONE;
+  double flops_train_bwd = 0;
 
   ~trebi_net() {
     for (void* p : allocs) (void)hipFree(p);
@@ -333,6 +387,7 @@ struct Builder {
   std::unordered_map<std::string, std::pair<const float*, int64_t>> sd;
   int dim, T;
   const float* temb = nullptr;      // device [T, dim]
+  bool train = false;               // training build: keep what the backward needs, record uploads and time jobs
 
   const float* host(const std::string& name, int64_t numel) {
     auto it = sd.find(name);
@@ -353,6 +408,7 @@ struct Builder {
       void* p = nullptr;
       if (hipMalloc(&p, sz) != hipSuccess) throw BadShape{"hipMalloc failed"};
       net->allocs.push_back(p);
+      net->alloc_bytes.push_back(sz);
       chunk = (char*)p;
       chunk_left = sz;
     }
@@ -364,6 +420,7 @@ struct Builder {
   const float* upload(const float* h, size_t n) {
     float* d = dalloc(n);
     if (hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) throw BadShape{"hipMemcpy failed"};
+    if (train) net->uploads.push_back({d, n});
     return d;
   }
   const float* upload(const std::vector<float>& v) { return upload(v.data(), v.size()); }
@@ -431,6 +488,7 @@ struct Builder {
     float* out = dalloc((size_t)T * N);
     if (launch_time_linear(w, ldw, col0, b, temb, dim, T, N, mish ? 1 : 0, out, 0) != hipSuccess)
       throw BadShape{"time table kernel launch failed"};
+    if (train) net->time_jobs.push_back({1, w, b, nullptr, nullptr, ldw, col0, N, mish ? 1 : 0, out});
     return out;
   }
 
@@ -608,6 +666,30 @@ struct Builder {
     return op;
   }
 
+  // Backward-to-input of Upsample1d = ConvTranspose1d(C, C, 4, 2, 1) [Cin, Cout, 4]: y[co, 2j+k-1] += x[ci, j] w[ci, co, k],
+  // so dX[ci, j] = sum_{co, k} dY[co, 2j + k - 1] w[ci, co, k]: a Conv1d(k=4, stride 2, pad 1) over dY (length 2*Lin).
+  Op convT_dgrad(const std::string& wname, int C, int Lin_fwd) {
+    Op op;
+    op.name = wname + " (dgrad)";
+    op.Lin = 2 * Lin_fwd;
+    op.Lout = Lin_fwd;
+    op.stride = 2;
+    op.pad = 1;
+    int lo, hi;
+    tap_range(op.Lin, op.Lout, 2, 1, 4, &lo, &hi);
+    op.tap_lo = lo;
+    op.ntaps = hi - lo + 1;
+    const float* w = host(wname + ".weight", (int64_t)C * C * 4);
+    std::vector<float> W((size_t)op.ntaps * C * C);
+    for (int tp = 0; tp < op.ntaps; ++tp)
+      for (int co = 0; co < C; ++co)
+        for (int ci = 0; ci < C; ++ci) W[((size_t)tp * C + co) * C + ci] = w[((size_t)ci * C + co) * 4 + lo + tp];
+    finish_geom(op, C, 0, C);
+    op.w = pack(W, op.ntaps, C, C, nullptr, 0);
+    op.flops = 2.0 * C * C * valid_pairs(op.Lin, op.Lout, 2, 1, lo, op.ntaps);
+    return op;
+  }
+
   // ---- ResidualTemporalBlock (temporal.py:18-46) -----------------------------------------
   struct RBRec {
     std::string prefix;
@@ -615,10 +697,12 @@ struct Builder {
     bool has_res;
     int y0, st0, y1, st1, g0, g1;
     GnW gn0, gn1;
+    RBInfo info;
   };
 
   RBRec res_block(const std::string& p, BufRef src, int cin, int cout, int L, BufRef dst, bool save) {
-    RBRec rec{p, cin, cout, L, cin != cout, NONE, NONE, NONE, NONE, NONE, NONE, {}, {}};
+    RBRec rec{p, cin, cout, L, cin != cout, NONE, NONE, NONE, NONE, NONE, NONE, {}, {}, {}};
+    save = save || train;
     std::string b0 = p + ".blocks.0.block", b1 = p + ".blocks.1.block";
     Op o0 = conv_fwd(b0 + ".0", cin, cout, 5, 1, 2, L, nullptr, 0);
     o0.gn = true;
@@ -637,13 +721,18 @@ struct Builder {
     if (save) {
       o0.save_y = rec.y0 = net->new_buf((size_t)L * cout);
       o0.save_st = rec.st0 = net->new_buf(2 * GN_GROUPS);
-      o0.save_g = rec.g0 = net->new_buf((size_t)L * cout);
       o1.save_y = rec.y1 = net->new_buf((size_t)L * cout);
       o1.save_st = rec.st1 = net->new_buf(2 * GN_GROUPS);
-      o1.save_g = rec.g1 = net->new_buf((size_t)L * cout);
+      if (!train) {                  // mish'(z)*gamma feeds the fused backward prologue; training recomputes it
+        o0.save_g = rec.g0 = net->new_buf((size_t)L * cout);
+        o1.save_g = rec.g1 = net->new_buf((size_t)L * cout);
+      }
     }
     net->fwd.push_back(o0);
     net->fwd.push_back(o1);
+    RBInfo& f = rec.info;
+    f.prefix = p; f.cin = cin; f.cout = cout; f.L = L; f.has_res = rec.has_res; f.src = src; f.dst = dst; f.a0 = a0;
+    f.y0 = rec.y0; f.st0 = rec.st0; f.y1 = rec.y1; f.st1 = rec.st1; f.gn0 = rec.gn0; f.gn1 = rec.gn1;
     return rec;
   }
 
@@ -674,6 +763,8 @@ struct Builder {
   }
 };
 
+void build_unet_train_bwd(Builder& B, const ArchPlan& a);     // trainer.inl
+
 void build_unet(Builder& B, const ArchPlan& a) {
   trebi_net* net = B.net;
   const trebi_net_desc& d = net->desc;
@@ -685,31 +776,34 @@ void build_unet(Builder& B, const ArchPlan& a) {
     L[i] = a.downs[i].L;
     if (i >= 1) cat[i] = net->new_buf((size_t)L[i] * 2 * C[i]);
   }
+  UnetRec& rec = net->rec;
   BufRef cur{EXT_X, 0, 0};
   for (int i = 0; i < n; ++i) {
     int rA = net->new_buf((size_t)L[i] * C[i]);
-    B.res_block("downs." + S(i) + ".0", cur, a.downs[i].cin, C[i], L[i], {rA, C[i], 0}, false);
+    rec.down0.push_back(B.res_block("downs." + S(i) + ".0", cur, a.downs[i].cin, C[i], L[i], {rA, C[i], 0}, false).info);
     BufRef skip = i >= 1 ? BufRef{cat[i], 2 * C[i], C[i]} : BufRef{net->new_buf((size_t)L[i] * C[i]), C[i], 0};
-    B.res_block("downs." + S(i) + ".1", {rA, C[i], 0}, C[i], C[i], L[i], skip, false);
+    rec.down1.push_back(B.res_block("downs." + S(i) + ".1", {rA, C[i], 0}, C[i], C[i], L[i], skip, false).info);
     cur = skip;
+    rec.downs.push_back({});
     if (a.downs[i].down) {
       Op dn = B.conv_fwd("downs." + S(i) + ".3.conv", C[i], C[i], 3, 2, 1, L[i], nullptr, 0);
       dn.src = cur;
       int db = net->new_buf((size_t)dn.Lout * C[i]);
       dn.dst = {db, C[i], 0};
       net->fwd.push_back(dn);
+      rec.downs.back() = {"downs." + S(i) + ".3.conv", C[i], L[i], cur, dn.dst};
       cur = {db, C[i], 0};
     }
   }
   int Lm = a.mid_L, Cm = a.mid_c;
   int m1 = net->new_buf((size_t)Lm * Cm);
-  B.res_block("mid_block1", cur, Cm, Cm, Lm, {m1, Cm, 0}, false);
+  rec.mid1 = B.res_block("mid_block1", cur, Cm, Cm, Lm, {m1, Cm, 0}, false).info;
   if (n == 1) {
     int m2 = net->new_buf((size_t)Lm * Cm);
-    B.res_block("mid_block2", {m1, Cm, 0}, Cm, Cm, Lm, {m2, Cm, 0}, false);
+    rec.mid2 = B.res_block("mid_block2", {m1, Cm, 0}, Cm, Cm, Lm, {m2, Cm, 0}, false).info;
     cur = {m2, Cm, 0};
   } else {
-    B.res_block("mid_block2", {m1, Cm, 0}, Cm, Cm, Lm, {cat[n - 1], 2 * C[n - 1], 0}, false);
+    rec.mid2 = B.res_block("mid_block2", {m1, Cm, 0}, Cm, Cm, Lm, {cat[n - 1], 2 * C[n - 1], 0}, false).info;
   }
   for (int k = 0; k < n - 1; ++k) {
     int j = n - 1 - k;
@@ -717,7 +811,9 @@ void build_unet(Builder& B, const ArchPlan& a) {
     int Lj = u.L;
     if (Lj != L[j]) unsupported("TemporalUnet skip length mismatch at level %d (%d vs %d)", j, Lj, L[j]);
     int u0 = net->new_buf((size_t)Lj * u.cout);
-    B.res_block("ups." + S(k) + ".0", {cat[j], 2 * C[j], 0}, u.cin, u.cout, Lj, {u0, u.cout, 0}, false);
+    rec.up0.push_back(B.res_block("ups." + S(k) + ".0", {cat[j], 2 * C[j], 0}, u.cin, u.cout, Lj, {u0, u.cout, 0}, false).info);
+    rec.catC.push_back(C[j]);
+    rec.ups.push_back({});
     int Lnext = u.up ? 2 * Lj : Lj;
     if (j - 1 >= 0 && Lnext != L[j - 1])
       unsupported("TemporalUnet up-path length %d does not match skip length %d", Lnext, L[j - 1]);
@@ -725,13 +821,14 @@ void build_unet(Builder& B, const ArchPlan& a) {
                                   : BufRef{net->new_buf((size_t)Lnext * u.cout), u.cout, 0};
     if (u.up) {
       int u1 = net->new_buf((size_t)Lj * u.cout);
-      B.res_block("ups." + S(k) + ".1", {u0, u.cout, 0}, u.cout, u.cout, Lj, {u1, u.cout, 0}, false);
+      rec.up1.push_back(B.res_block("ups." + S(k) + ".1", {u0, u.cout, 0}, u.cout, u.cout, Lj, {u1, u.cout, 0}, false).info);
       Op up = B.convT_fwd("ups." + S(k) + ".3.conv", u.cout, Lj);
       up.src = {u1, u.cout, 0};
       up.dst = nextdst;
       net->fwd.push_back(up);
+      rec.ups.back() = {"ups." + S(k) + ".3.conv", u.cout, Lj, up.src, nextdst};
     } else {
-      B.res_block("ups." + S(k) + ".1", {u0, u.cout, 0}, u.cout, u.cout, Lj, nextdst, false);
+      rec.up1.push_back(B.res_block("ups." + S(k) + ".1", {u0, u.cout, 0}, u.cout, u.cout, Lj, nextdst, false).info);
     }
     cur = nextdst;
   }
@@ -743,12 +840,18 @@ void build_unet(Builder& B, const ArchPlan& a) {
   f0.src = cur;
   int fb = net->new_buf((size_t)Lf * dim);
   f0.dst = {fb, dim, 0};
+  rec.final_src = cur; rec.final_fb = fb; rec.final_L = Lf; rec.final_gn = f0.gnw;
+  if (B.train) {
+    f0.save_y = rec.final_y = net->new_buf((size_t)Lf * dim);
+    f0.save_st = rec.final_st = net->new_buf(2 * GN_GROUPS);
+  }
   net->fwd.push_back(f0);
   Op f1 = B.conv_fwd("final_conv.1", dim, d.transition_dim, 1, 1, 0, Lf, nullptr, 0);
   f1.src = {fb, dim, 0};
   f1.dst = {EXT_OUT, 0, 0};
   net->fwd.push_back(f1);
   if (Lf != d.horizon) unsupported("TemporalUnet output length %d != horizon %d", Lf, d.horizon);
+  if (B.train) build_unet_train_bwd(B, a);
 }
 
 void build_value(Builder& B, const ArchPlan& a) {
@@ -1510,9 +1613,9 @@ extern "C" int trebi_net_param_info(const trebi_net_desc* desc, int i, char* nam
   return 0;
 }
 
-extern "C" int trebi_net_create(trebi_ctx* ctx, const trebi_net_desc* desc, const char* const* names,
-                                const float* const* tensors, const int64_t* numels, int n_tensors,
-                                trebi_net** out) {
+static int net_create_impl(trebi_ctx* ctx, const trebi_net_desc* desc, const char* const* names,
+                           const float* const* tensors, const int64_t* numels, int n_tensors, bool train,
+                           trebi_net** out) {
   if (!ctx || !out || !names || !tensors || !numels) return fail(TREBI_BAD_ARG, "null argument");
   if (int e = check_desc(desc)) return e;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1521,10 +1624,12 @@ extern "C" int trebi_net_create(trebi_ctx* ctx, const trebi_net_desc* desc, cons
   net->ctx = ctx;
   net->desc = *desc;
   net->T = desc->max_timesteps;
+  net->train = train;
   Builder B;
   B.net = net.get();
   B.dim = desc->dim;
   B.T = net->T;
+  B.train = train;
   for (int i = 0; i < n_tensors; ++i) {
     if (!names[i] || !tensors[i]) return fail(TREBI_BAD_ARG, "tensor table entry %d is null", i);
     B.sd[names[i]] = {tensors[i], numels[i]};
@@ -1545,7 +1650,15 @@ extern "C" int trebi_net_create(trebi_ctx* ctx, const trebi_net_desc* desc, cons
     const float* w2 = B.upload(B.host("time_mlp.3.weight", (int64_t)4 * dim * dim), (size_t)4 * dim * dim);
     const float* b2 = B.upload(B.host("time_mlp.3.bias", dim), dim);
     float* temb = B.dalloc((size_t)net->T * dim);
-    HIPCHK(launch_time_embed(w1, b1, w2, b2, dim, net->T, temb, 0));
+    if (train) {                     // the backward of time_mlp needs the embedding and the pre-activation too
+      net->tt_e = B.dalloc((size_t)net->T * dim);
+      net->tt_a1 = B.dalloc((size_t)net->T * 4 * dim);
+      net->tt_temb = temb;
+      HIPCHK(launch_time_embed_train(w1, b1, w2, b2, dim, net->T, net->tt_e, net->tt_a1, temb, 0));
+      net->time_jobs.push_back({0, w1, b1, w2, b2, 0, 0, 0, 0, temb});
+    } else {
+      HIPCHK(launch_time_embed(w1, b1, w2, b2, dim, net->T, temb, 0));
+    }
     B.temb = temb;
     ArchPlan a = make_arch(*desc);
     if (desc->kind == 0) build_unet(B, a); else build_value(B, a);
@@ -1563,6 +1676,11 @@ extern "C" int trebi_net_create(trebi_ctx* ctx, const trebi_net_desc* desc, cons
   HIPCHK(hipDeviceSynchronize());
   *out = net.release();
   return 0;
+}
+extern "C" int trebi_net_create(trebi_ctx* ctx, const trebi_net_desc* desc, const char* const* names,
+                                const float* const* tensors, const int64_t* numels, int n_tensors,
+                                trebi_net** out) {
+  return net_create_impl(ctx, desc, names, tensors, numels, n_tensors, false, out);
 }
 extern "C" void trebi_net_destroy(trebi_net* net) { delete net; }
 
@@ -2004,3 +2122,8 @@ extern "C" int trebi_sampler_get_profile(trebi_sampler* s, double* gemm_us_total
 extern "C" double trebi_net_flops(const trebi_net* net, int backward) {
   return net ? (backward ? net->flops_bwd : net->flops_fwd) : 0.0;
 }
+
+// ------------------------------------------------------------------------------------
+// the training step: host side
+// ------------------------------------------------------------------------------------
+#include "trainer.inl"

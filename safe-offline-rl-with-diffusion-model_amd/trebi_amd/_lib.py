@@ -31,6 +31,12 @@ class SamplerDesc(C.Structure):
                 ('skip_dead_evals', C.c_int)]
 
 
+class TrainDesc(C.Structure):
+    _fields_ = [('horizon', C.c_int), ('observation_dim', C.c_int), ('action_dim', C.c_int), ('n_timesteps', C.c_int),
+                ('dim', C.c_int), ('n_mults', C.c_int), ('dim_mults', C.c_int * 8), ('predict_epsilon', C.c_int),
+                ('loss_l1', C.c_int), ('n_cond', C.c_int), ('cond_index', C.c_int * 4)]
+
+
 # name -> (restype, argtypes); every symbol the header declares
 _VP = C.c_void_p
 SIGNATURES = {
@@ -64,6 +70,15 @@ SIGNATURES = {
     'trebi_sampler_set_profiling': (C.c_int, [_VP, C.c_int]),
     'trebi_sampler_get_profile': (C.c_int, [_VP, C.POINTER(C.c_double), c_i64_p, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double)]),
+    'trebi_trainer_create': (C.c_int, [_VP, C.POINTER(TrainDesc), C.c_int, C.POINTER(_VP)]),
+    'trebi_trainer_destroy': (None, [_VP]),
+    'trebi_trainer_param_count': (C.c_int64, [_VP]),
+    'trebi_trainer_flops': (C.c_double, [_VP, C.c_int]),
+    'trebi_trainer_bind': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, c_float_p, c_float_p, c_float_p]),
+    'trebi_trainer_repack': (C.c_int, [_VP, _VP]),
+    'trebi_trainer_accumulate': (C.c_int, [_VP, _VP, C.POINTER(_VP), _VP, _VP, C.c_int, C.c_float, _VP, _VP]),
+    'trebi_trainer_step': (C.c_int, [_VP, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float,
+                                     _VP]),
 }
 
 _lib = None

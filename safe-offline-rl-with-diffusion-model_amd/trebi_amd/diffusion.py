@@ -517,6 +517,34 @@ class GaussianDiffusion(nn.Module):
         shape = (batch_size, horizon, self.transition_dim)
         return self.p_sample_loop(shape, cond, **sample_kwargs)
 
+    # ------------------------------------------------------------------ training
+    def train_engine(self, max_batch=None, ema_model=None):
+        """The library object behind loss(): flat parameter / gradient buffers + the fused forward-loss-backward
+        (trebi_amd/training.py).  One per model: the TemporalUnet's parameters become views of its flat buffer."""
+        from .training import TrainEngine
+        eng = getattr(self, '_engine', None)
+        if eng is None:
+            if max_batch is None:
+                raise RuntimeError('no training engine yet: call train_engine(max_batch) or build a training.Trainer')
+            eng = self._engine = TrainEngine(self, max_batch, ema_model=ema_model)
+        elif max_batch is not None and max_batch > eng.max_batch:
+            raise RuntimeError(f'the training engine was sized for batches of {eng.max_batch}, got {max_batch}')
+        return eng
+
+    def p_losses(self, x_start, cond, t, noise=None, grad_scale=1.0):                     # diffusion.py:240-256
+        """Returns (loss, {'a0_loss': ...}) like the reference -- and, because forward, loss and backward are ONE
+        fused library call here, ALSO adds grad_scale * dloss/dparams to the engine's flat gradient (what the
+        reference does later in loss.backward(), training.py:115-116)."""
+        eng = self.train_engine(len(x_start))
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        out = eng.accumulate(x_start, cond, t, noise, grad_scale=grad_scale)
+        return out[0], {'a0_loss': out[1]}
+
+    def loss(self, x, *args, **kw):                                                       # diffusion.py:258-261
+        t = torch.randint(0, self.n_timesteps, (len(x),), device=x.device).long()
+        return self.p_losses(x, *args, t, **kw)
+
     def forward(self, cond, *args, **kwargs):                                             # diffusion.py:263-264
         return self.conditional_sample(cond, *args, **kwargs)
 
