@@ -197,6 +197,8 @@ struct WgP {
   int NB;                          // 16-channel B tiles per workgroup (1, 2 or 4)
   int SA, SB, ldAs, ldBs;          // LDS strides (floats): per candidate / per row
   int CA16, CB16, vecA, vecB;
+  unsigned mLA, mLB;               // magic multipliers of LA, LB (0 for 1)
+  int pf;                          // 1: the next chunk is prefetched into registers behind the MFMA loop
   float* slab; long slab_stride;   // floats per ks slice = k*CB16*CA16
 };
 hipError_t train_init_device();

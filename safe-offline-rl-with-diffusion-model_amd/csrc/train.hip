@@ -109,20 +109,20 @@ __device__ __forceinline__ float stride_sum(float v, int g4) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void gnb_kernel(GnbP p) {
+__global__ __launch_bounds__(1024) void gnb_kernel(GnbP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int C = p.C, T = p.T;
   float* colacc = sm;                       // [3][C]
   float* ttab = sm + 3 * C;                 // [T][C]
   const int nt = 3 * C + (p.ptime ? T * C : 0);
-  for (int i = threadIdx.x; i < nt; i += 256) sm[i] = 0.f;
+  for (int i = threadIdx.x; i < nt; i += 1024) sm[i] = 0.f;
   __syncthreads();
-  const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;
+  const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;      // 64 teams of 16 lanes
   const int gch = p.gch, g4 = gch >> 2, L = p.L, cnt4 = L * g4;
   const float icnt = 1.f / (float)(cnt4 * 4);
   const int ninst = p.B * GN_GROUPS;
   const int c4 = tl & (g4 - 1);             // the float4 column of this lane inside the group (16 % g4 == 0)
-  for (int inst = blockIdx.x * 16 + team; inst < ninst; inst += gridDim.x * 16) {
+  for (int inst = blockIdx.x * 64 + team; inst < ninst; inst += gridDim.x * 64) {
     const int b = inst >> 3, gi = inst & 7;
     const int c = gi * gch + 4 * c4;
     const float rstd = gld(p.stats + 2 * inst + 1);
@@ -185,13 +185,13 @@ __global__ __launch_bounds__(256) void gnb_kernel(GnbP p) {
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 3 * C; i += 256) gst(p.pcol + (size_t)blockIdx.x * 3 * C + i, colacc[i]);
+  for (int i = threadIdx.x; i < 3 * C; i += 1024) gst(p.pcol + (size_t)blockIdx.x * 3 * C + i, colacc[i]);
   if (p.ptime)
-    for (int i = threadIdx.x; i < T * C; i += 256) gst(p.ptime + (size_t)blockIdx.x * T * C + i, ttab[i]);
+    for (int i = threadIdx.x; i < T * C; i += 1024) gst(p.ptime + (size_t)blockIdx.x * T * C + i, ttab[i]);
 }
 hipError_t launch_gnb(const GnbP& p, int nblk, hipStream_t st) {
   const size_t lds = (size_t)(3 * p.C + (p.ptime ? p.T * p.C : 0)) * sizeof(float);
-  hipLaunchKernelGGL(gnb_kernel, dim3(nblk), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(gnb_kernel, dim3(nblk), dim3(1024), lds, st, p);
   return hipGetLastError();
 }
 
@@ -228,8 +228,16 @@ hipError_t launch_colsum(const float* src, int ld, long rows, int C, float* part
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(const RJob* jobs) {
   const RJob j = jobs[blockIdx.y];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < j.n; i += gridDim.x * 256) {
-    float a = 0.f;
-    for (int b = 0; b < j.nblk; ++b) a += gld(j.src + (size_t)b * j.stride + i);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 3 < j.nblk; b += 4) {
+      a0 += gld(j.src + (size_t)b * j.stride + i);
+      a1 += gld(j.src + (size_t)(b + 1) * j.stride + i);
+      a2 += gld(j.src + (size_t)(b + 2) * j.stride + i);
+      a3 += gld(j.src + (size_t)(b + 3) * j.stride + i);
+    }
+    for (; b < j.nblk; ++b) a0 += gld(j.src + (size_t)b * j.stride + i);
+    const float a = (a0 + a1) + (a2 + a3);
     j.dst[i] = j.assign ? a : j.dst[i] + a;
   }
 }
@@ -260,7 +268,7 @@ hipError_t launch_add_cols(float* dst, int ldd, const float* src, int lds, long 
 // weight gradient GEMM
 // =====================================================================================================
 template <int NB>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {      // two workgroups per CU: at most 256 VGPRs
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, lr = lane & 15;
@@ -280,31 +288,77 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
     for (int nb = 0; nb < NB; ++nb) acc[tp][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int ta4 = TA / 4, tb4 = TB / 4;
   const int stride = p.stride, pad = p.pad, k = p.k;
-  for (int s0 = s_begin; s0 < s_end; s0 += S) {
-    // ---- stage S candidates: A rows [s][pos][TA], B rows [s][l][TB]; zero beyond the batch / the channels ----
-    {
-      const int nA = S * LA * ta4;
-      for (int i = tid; i < nA; i += nthr) {
-        const int row = i / ta4, c4 = i - row * ta4;
-        const int s = row / LA, pos = row - s * LA;
-        const int ch = ca0 + 4 * c4;
-        const int left = (s0 + s < s_end) ? p.CA - ch : 0;
-        const float* sp = p.A + ((size_t)(s0 + s) * LA + pos) * p.ldA + ch;
-        const f32x4 v = p.vecA ? load4<true>(sp, left) : load4<false>(sp, left);
-        *(f32x4*)&As[s * SA + pos * ldAs + 4 * c4] = v;
-      }
-      const int nB = S * LB * tb4;
-      for (int i = tid; i < nB; i += nthr) {
-        const int row = i / tb4, c4 = i - row * tb4;
-        const int s = row / LB, l = row - s * LB;
-        const int ch = cb0 + 4 * c4;
-        const int left = (s0 + s < s_end) ? p.CB - ch : 0;
-        const float* sp = p.Bm + ((size_t)(s0 + s) * LB + l) * p.ldB + ch;
-        const f32x4 v = p.vecB ? load4<true>(sp, left) : load4<false>(sp, left);
-        *(f32x4*)&Bs[s * SB + l * ldBs + 4 * c4] = v;
-      }
+  // Staging is software-pipelined: the global loads of the NEXT chunk of S candidates are issued (into registers)
+  // before the MFMA loop of the current one and written to LDS after it, so their latency hides behind the matrix
+  // work.  At most 8 float4 per thread and operand (the host sizes S for that).
+  constexpr int U = 8;
+  f32x4 ra[U], rb[U];
+  const int nA = S * LA * ta4, nB = S * LB * tb4;
+  // a thread's float4 column is fixed and its rows advance by a constant (nthr is a multiple of ta4 and tb4)
+  const int c4a = tid % ta4, rowa0 = tid / ta4, rstepA = nthr / ta4;
+  const int c4b = tid % tb4, rowb0 = tid / tb4, rstepB = nthr / tb4;
+  const bool chA = ca0 + 4 * c4a < p.CA, chB = cb0 + 4 * c4b < p.CB;
+  const FastDiv dLA(LA, p.mLA), dLB(LB, p.mLB);
+  const int spadA = SA - LA * ldAs, spadB = SB - LB * ldBs;
+  auto fetch = [&](int s0) {                  // (vectorisable operands only: the host checks)
+    int r0 = rowa0, r1 = rowb0;
+    asm volatile("" : "+v"(r0), "+v"(r1));    // keep the per-item index math inside the chunk loop (registers)
+    const int ns = s_end - s0 < S ? s_end - s0 : S;
+    const float* ba = p.A + (size_t)s0 * LA * p.ldA;
+    const float* bb = p.Bm + (size_t)s0 * LB * p.ldB;
+    const unsigned oa = (unsigned)(ca0 + 4 * c4a), ob = (unsigned)(cb0 + 4 * c4b);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r0 + u * rstepA;
+      ra[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (chA && row < ns * LA) ra[u] = gld4(ba + ((unsigned)row * (unsigned)p.ldA + oa));
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r1 + u * rstepB;
+      rb[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (chB && row < ns * LB) rb[u] = gld4(bb + ((unsigned)row * (unsigned)p.ldB + ob));
+    }
+  };
+  auto commit = [&]() {
+    int r0 = rowa0, r1 = rowb0;
+    asm volatile("" : "+v"(r0), "+v"(r1));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r0 + u * rstepA;
+      if (row < S * LA) *(f32x4*)&As[row * ldAs + (int)dLA.div(row) * spadA + 4 * c4a] = ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r1 + u * rstepB;
+      if (row < S * LB) *(f32x4*)&Bs[row * ldBs + (int)dLB.div(row) * spadB + 4 * c4b] = rb[u];
+    }
+  };
+  // narrow layers (few waves, long rows) exceed the register budget: they stage synchronously
+  auto stage_sync = [&](int s0) {
+    for (int i = tid; i < nA; i += nthr) {
+      const int row = i / ta4, c4 = i - row * ta4;
+      const int s = row / LA, pos = row - s * LA;
+      const int ch = ca0 + 4 * c4;
+      const int left = (s0 + s < s_end) ? p.CA - ch : 0;
+      const float* sp = p.A + ((size_t)s0 * LA + row) * p.ldA + ch;
+      *(f32x4*)&As[s * SA + pos * ldAs + 4 * c4] = p.vecA ? load4<true>(sp, left) : load4<false>(sp, left);
+    }
+    for (int i = tid; i < nB; i += nthr) {
+      const int row = i / tb4, c4 = i - row * tb4;
+      const int s = row / LB, l = row - s * LB;
+      const int ch = cb0 + 4 * c4;
+      const int left = (s0 + s < s_end) ? p.CB - ch : 0;
+      const float* sp = p.Bm + ((size_t)s0 * LB + row) * p.ldB + ch;
+      *(f32x4*)&Bs[s * SB + l * ldBs + 4 * c4] = p.vecB ? load4<true>(sp, left) : load4<false>(sp, left);
+    }
+  };
+  const bool pf = p.pf != 0;
+  if (pf && s_begin < s_end) fetch(s_begin);
+  for (int s0 = s_begin; s0 < s_end; s0 += S) {
+    if (pf) commit(); else stage_sync(s0);
     __syncthreads();
+    if (pf && s0 + S < s_end) fetch(s0 + S);
     // ---- MFMA: k-slot g of an instruction = candidate 4*sq + g, all four at the same position ----
     const float* aw = As + g * SA + wave * 16 + lr;
     const float* bw = Bs + g * SB + lr;
@@ -353,7 +407,8 @@ hipError_t train_init_device() {
 }
 
 hipError_t launch_wgrad(const WgP& p, int ksplit, hipStream_t st) {
-  if (p.k > 5 || p.nwa < 1 || p.nwa > 4 || p.S % 4 || p.CA16 % (16 * p.nwa) || p.CB16 % (16 * p.NB))
+  if (p.k > 5 || p.nwa < 1 || p.nwa > 4 || p.S % 4 || p.CA16 % (16 * p.nwa) || p.CB16 % (16 * p.NB) ||
+      (p.pf && (p.S * p.LA * 4 * p.nwa > 8 * 64 * p.nwa || p.S * p.LB * 4 * p.NB > 8 * 64 * p.nwa)))   // 8 float4 per thread
     return hipErrorInvalidValue;
   const size_t lds = (size_t)p.S * (p.SA + p.SB) * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -368,24 +423,47 @@ hipError_t launch_wgrad(const WgP& p, int ksplit, hipStream_t st) {
 }
 
 // grad[(cb*CA + ca)*k + tap] += sum_ks slab[ks][tap][cb][ca]
-__global__ __launch_bounds__(256) void wreduce_kernel(const float* slab, int ksplit, long slab_stride, int k, int CA,
-                                                      int CB, int CA16, int CB16, float* grad) {
-  const long n = (long)k * CB16 * CA16;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int ca = (int)(i % CA16);
-    const long r = i / CA16;
+// A workgroup owns 64 float4 columns of the slab; its 16 waves each sum every 16th slab (four loads in flight per
+// lane), the partial sums meet in LDS in a fixed order (bitwise reproducible), then one scattered add per element.
+__global__ __launch_bounds__(1024) void wreduce_kernel(const float* slab, int ksplit, long slab_stride, int k, int CA,
+                                                       int CB, int CA16, int CB16, float* grad) {
+  __shared__ f32x4 part[16][64];
+  const int e4 = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const long n4 = (long)k * CB16 * (CA16 / 4);
+  const long i4 = (long)blockIdx.x * 64 + e4;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (i4 < n4) {
+    const float* p = slab + 4 * i4;
+    int s = ks;
+    for (; s + 48 < ksplit; s += 64) {
+      a0 += gld4(p + (size_t)s * slab_stride);
+      a1 += gld4(p + (size_t)(s + 16) * slab_stride);
+      a2 += gld4(p + (size_t)(s + 32) * slab_stride);
+      a3 += gld4(p + (size_t)(s + 48) * slab_stride);
+    }
+    for (; s < ksplit; s += 16) a0 += gld4(p + (size_t)s * slab_stride);
+  }
+  part[ks][e4] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (ks == 0 && i4 < n4) {
+    f32x4 a = part[0][e4];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) a += part[j][e4];
+    const int ca = (int)(i4 % (CA16 / 4)) * 4;
+    const long r = i4 / (CA16 / 4);
     const int cb = (int)(r % CB16), tp = (int)(r / CB16);
-    if (ca >= CA || cb >= CB) continue;
-    float a = 0.f;
-    for (int s = 0; s < ksplit; ++s) a += gld(slab + (size_t)s * slab_stride + i);
-    grad[((size_t)cb * CA + ca) * k + tp] += a;
+    if (cb < CB) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ca + q < CA) grad[((size_t)cb * CA + ca + q) * k + tp] += a[q];
+    }
   }
 }
 hipError_t launch_wreduce(const float* slab, int ksplit, long slab_stride, int k, int CA, int CB, int CA16, int CB16,
                           float* grad, hipStream_t st) {
-  const long n = (long)k * CB16 * CA16;
-  int blocks = (int)std::min<long>((n + 255) / 256, 2048);
-  hipLaunchKernelGGL(wreduce_kernel, dim3(blocks), dim3(256), 0, st, slab, ksplit, slab_stride, k, CA, CB, CA16, CB16, grad);
+  const long n4 = (long)k * CB16 * (CA16 / 4);
+  hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(1024), 0, st, slab, ksplit, slab_stride, k, CA,
+                     CB, CA16, CB16, grad);
   return hipGetLastError();
 }
 
@@ -488,27 +566,32 @@ hipError_t launch_time_embed_train(const float* w1, const float* b1, const float
 //            DT[t][k] = sum_c G[t][c] * Wt[c][k]      (the block's contribution to d mish(temb))
 __global__ __launch_bounds__(256) void time_block_bwd_kernel(const TBJob* jobs, const float* temb, int dim, int T) {
   const TBJob j = jobs[blockIdx.x];
-  const int C = j.C;
-  for (int i = threadIdx.x; i < C * dim; i += 256) {
+  const int C = j.C, tid = blockIdx.y * 256 + threadIdx.x, nthr = gridDim.y * 256;
+  for (int i = tid; i < C * dim; i += nthr) {
     const int c = i / dim, k = i - c * dim;
     float a = 0.f;
-    for (int t = 0; t < T; ++t) a = fmaf(j.G[t * C + c], mish_f(temb[t * dim + k]), a);
+    for (int t = 0; t < T; ++t) a = fmaf(gld(j.G + t * C + c), mish_f(gld(temb + t * dim + k)), a);
     j.gW[i] += a;
   }
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = tid; c < C; c += nthr) {
     float a = 0.f;
-    for (int t = 0; t < T; ++t) a += j.G[t * C + c];
+    for (int t = 0; t < T; ++t) a += gld(j.G + t * C + c);
     j.gb[c] += a;
   }
-  for (int i = threadIdx.x; i < T * dim; i += 256) {
+  for (int i = tid; i < T * dim; i += nthr) {
     const int t = i / dim, k = i - t * dim;
-    float a = 0.f;
-    for (int c = 0; c < C; ++c) a = fmaf(j.G[t * C + c], j.Wt[c * dim + k], a);
-    j.DT[i] = a;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c = 0; c < C; c += 4) {               // C is a multiple of 32
+      a0 = fmaf(gld(j.G + t * C + c), gld(j.Wt + c * dim + k), a0);
+      a1 = fmaf(gld(j.G + t * C + c + 1), gld(j.Wt + (c + 1) * dim + k), a1);
+      a2 = fmaf(gld(j.G + t * C + c + 2), gld(j.Wt + (c + 2) * dim + k), a2);
+      a3 = fmaf(gld(j.G + t * C + c + 3), gld(j.Wt + (c + 3) * dim + k), a3);
+    }
+    j.DT[i] = (a0 + a1) + (a2 + a3);
   }
 }
 hipError_t launch_time_block_bwd(const TBJob* dev_jobs, int njobs, const float* temb, int dim, int T, hipStream_t st) {
-  hipLaunchKernelGGL(time_block_bwd_kernel, dim3(njobs), dim3(256), 0, st, dev_jobs, temb, dim, T);
+  hipLaunchKernelGGL(time_block_bwd_kernel, dim3(njobs, 8), dim3(256), 0, st, dev_jobs, temb, dim, T);
   return hipGetLastError();
 }
 

@@ -197,7 +197,7 @@ void build_unet_train_bwd(Builder& B, const ArchPlan& a) {
 }
 
 struct WgCfg {
-  int nwa, NB, S, spw, ksplit, SA, SB, ldAs, ldBs, CA16, CB16;
+  int nwa, NB, S, spw, ksplit, SA, SB, ldAs, ldBs, CA16, CB16, pf;
   size_t slab;                      // floats
   long slab_stride;
 };
@@ -212,11 +212,15 @@ WgCfg wg_config(const TOp& t, int B) {
   c.SA = pad16(t.LA * c.ldAs); c.SB = pad16(t.LB * c.ldBs);
   int S = (72 * 1024 / 4) / (c.SA + c.SB) / 4 * 4;
   S = std::max(4, std::min(64, S));
+  // the kernel prefetches the next chunk into registers where that takes at most 8 float4 per thread and operand
+  const int Spf = std::min(std::min(S, 128 / t.LA / 4 * 4), 128 * c.nwa / (t.LB * c.NB) / 4 * 4);
+  c.pf = Spf >= 4;
+  if (c.pf) S = Spf;
   if ((size_t)S * (c.SA + c.SB) * sizeof(float) > 160 * 1024)
-    unsupported("weight gradient of a length-%d layer does not fit LDS", std::max(t.LA, t.LB));
+    unsupported("weight gradient of a layer of length %d (%d x %d channels) is not tiled", std::max(t.LA, t.LB), t.CA, t.CB);
   c.S = S;
   const int ntiles = (c.CA16 / (16 * c.nwa)) * (c.CB16 / (16 * c.NB));
-  int ks = std::max(1, std::min((1024 + ntiles - 1) / ntiles, (B + S - 1) / S));
+  int ks = std::max(1, std::min((512 + ntiles - 1) / ntiles, (B + S - 1) / S));      // ~two workgroups per CU
   c.spw = rup((B + ks - 1) / ks, S);
   c.ksplit = (B + c.spw - 1) / c.spw;
   c.slab_stride = (long)t.k * c.CB16 * c.CA16;
@@ -548,6 +552,9 @@ extern "C" int trebi_trainer_accumulate(trebi_trainer* tr, const float* x_start,
         w.vecA = ((w.ldA & 3) == 0) && ((t.CA & 3) == 0) && ((((uintptr_t)w.A) & 15) == 0);
         w.vecB = ((w.ldB & 3) == 0) && ((t.CB & 3) == 0) && ((((uintptr_t)w.Bm) & 15) == 0);
         w.slab = tr->wslab; w.slab_stride = c.slab_stride;
+        w.pf = c.pf && w.vecA && w.vecB;
+        w.mLA = t.LA > 1 ? 0xFFFFFFFFu / (unsigned)t.LA + 1u : 0u;
+        w.mLB = t.LB > 1 ? 0xFFFFFFFFu / (unsigned)t.LB + 1u : 0u;
         if (!w.A || !w.Bm) return fail(TREBI_HIP_ERROR, "internal: unresolved operand at %s", t.name.c_str());
         HIPCHK(launch_wgrad(w, c.ksplit, st));
         HIPCHK(launch_wreduce(tr->wslab, c.ksplit, c.slab_stride, t.k, t.CA, t.CB, c.CA16, c.CB16, tr->grads + t.off_w, st));
