@@ -54,20 +54,24 @@ def build_models(device):
     return diff, guide, cguide, (sd_u, sd_r, sd_c)
 
 
-def other_configs(device, steps=3):
-    """BASELINE configs 3 and 4 at their PER-GPU size (the driver's scaling runs use the headline config): whole planning
-    calls through the same ShardedPlanner path, synthetic seeded weights.  Reported next to the headline, not as `value`."""
+def other_configs(device, steps=3, world=1, rank=0, rehearse=False):
+    """BASELINE configs 3 and 4, whole planning calls through the same ShardedPlanner path, synthetic seeded weights.
+    One GPU: at their PER-GPU size (512 and 8192 candidates).  world > 1: at their GLOBAL size (4096 and 65536 candidates)
+    sharded over the ranks -- strong scaling, with the score all-gather in the loop.  Reported next to the headline, not as `value`."""
     from trebi_amd import spec, synth
-    from trebi_amd.parallel import ShardedPlanner
+    from trebi_amd.parallel import ShardedPlanner, shard_bounds
     from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
     from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
     out = []
-    for name, obs, act, um, vm, B, kw in (
-            ('configs[2]: hopper-medium-v2 shapes, 4096 candidates / 8 GPUs', 11, 3, (1, 2, 4, 8), (1, 2, 4, 8), 512,
+    for name, obs, act, um, vm, Bgpu, Bglobal, kw in (
+            ('configs[2]: hopper-medium-v2 shapes, 4096 candidates / 8 GPUs', 11, 3, (1, 2, 4, 8), (1, 2, 4, 8), 512, 4096,
              dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0)),
             ('configs[3]: walker2d shapes, UNet dim_mults (1,4,8), 65536 candidates / 8 GPUs', 17, 6, (1, 4, 8),
-             (1, 2, 4, 8), 8192, dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0))):
+             (1, 2, 4, 8), 8192, 65536, dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0))):
         D = obs + act
+        n_global = Bgpu if world == 1 else (min(Bglobal, 8192) if rehearse else Bglobal)
+        lo, hi = shard_bounds(n_global, world, rank)
+        B = hi - lo
 
         def mk(cls, shapes, seed, mults):
             net = cls(H, D, 0, dim=DIM, dim_mults=mults)
@@ -81,22 +85,37 @@ def other_configs(device, steps=3):
         cguide = ValueGuide(ValueDiffusion(mk(ValueFunction, spec.value_param_shapes(H, D, DIM, vm), 102, vm), H, obs, act,
                                            **dkw)).to(device)
         o = torch.from_numpy(np.random.default_rng(1).standard_normal(obs).astype(np.float32)).to(device)
-        x_T = torch.randn(B, H, D, device=device, generator=torch.Generator(device).manual_seed(2))
+        nb = min(max(B, 1), 512)
+        x_T = torch.randn(nb, H, D, device=device, generator=torch.Generator(device).manual_seed(2))
         x_T[:, 0, act:] = o
-        thr = float(cguide(x_T, None, torch.full((B,), T - 1, device=device, dtype=torch.long)).median())
+        tt = cguide(x_T, None, torch.full((nb,), T - 1, device=device, dtype=torch.long)).median().reshape(1)
+        if world > 1:
+            dist.broadcast(tt, 0)
+        thr = float(tt)
         planner = ShardedPlanner(diff)
-        run = lambda: planner.plan(o, B, H, fn, cost_threshold=thr, guide=guide, cost_guide=cguide, **kw)
+        run = lambda: planner.plan(o, n_global, H, fn, cost_threshold=thr, guide=guide, cost_guide=cguide, copy=False, **kw)
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(device)
         run()
-        torch.cuda.synchronize(device)
+        fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             run()
-        torch.cuda.synchronize(device)
+        fence()
         dt = (time.perf_counter() - t0) / steps
+        if world > 1:
+            td = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            dt = float(td)
         fl = T * (unet.flops() + 2 * kw['n_guide_steps'] * (guide._net().flops() + guide._net().flops(backward=True)))
-        tf = fl * B / dt / 1e12
-        out.append({'workload': f'{name}: {B} candidates on this GPU', 'trajectories_per_s': B / dt, 'ms_per_step': 1e3 * dt,
-                    'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F32_MFMA_TFLOPS})
+        tf = fl * n_global / dt / 1e12
+        out.append({'workload': f'{name}: {n_global} candidates over {world} GPU(s), {B} on this rank',
+                    'trajectories_per_s': n_global / dt, 'ms_per_step': 1e3 * dt, 'scaling': 'strong' if world > 1 else 'per-GPU size',
+                    'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS * world, 'unit': 'TFLOP/s',
+                    'frac': tf / (PEAK_F32_MFMA_TFLOPS * world)})
         del planner, diff, guide, cguide, unet
         torch.cuda.empty_cache()
     return out
@@ -122,9 +141,88 @@ def unet_utilisation(unet, device, batch=8192, iters=10):
             'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F32_MFMA_TFLOPS}
 
 
-def cpu_baseline(sds, B, thr, runs=2):
-    """The numpy oracle (a port of the reference path, oracle/trebi_oracle.py) on this box's host cores:
-    the same workload (B candidates, full 20-step constrained loop), `runs` times."""
+def train_step_extra(device, world, rank, batch=4096, accum=2, steps=4, cpu=True):
+    """BASELINE configs[4]: the denoiser's training step (halfcheetah shapes, micro-batch 4096, gradient_accumulate_every 2 as in
+    config/locomotion.py:49-50) -- q_sample, TemporalUnet forward, weighted L2, full backward, Adam, EMA.  Data-parallel under
+    world > 1: the GLOBAL micro-batch stays 4096 (strong scaling), each rank takes 4096 / world samples, one all-reduce of the
+    flat gradient per optimiser step.  Reported next to the headline, never as `value`."""
+    from trebi_amd import spec, synth
+    from trebi_amd.training import Trainer
+    from diffuser.models import TemporalUnet, GaussianDiffusion
+    D = OBS + ACT
+    unet = TemporalUnet(H, D, 0, dim=DIM, dim_mults=MULTS)
+    sd = synth.synth_state_dict(spec.unet_param_shapes(H, D, DIM, MULTS), 100)
+    unet.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    diff = GaussianDiffusion(unet, H, OBS, ACT, n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False,
+                             action_weight=10.0).to(device)
+    from trebi_amd.parallel import shard_bounds
+    lo, hi = shard_bounds(batch, world, rank)
+    Bl = hi - lo
+    tr = Trainer(diff, train_batch_size=max(Bl, 1), train_lr=2e-4, gradient_accumulate_every=accum, distributed=world > 1)
+    g = torch.Generator(device).manual_seed(rank)
+    data = []
+    for _ in range(accum):
+        x = torch.randn(Bl, H, D, device=device, generator=g)
+        data.append((x, {0: x[:, 0, ACT:].contiguous()}))
+    sizes = [batch] * accum
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+    for _ in range(2):
+        tr.train_step(data, global_batch_sizes=sizes)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = tr.train_step(data, global_batch_sizes=sizes)     # t ~ randint, noise ~ randn drawn inside, like loss()
+    fence()
+    dt = (time.perf_counter() - t0) / steps
+    if world > 1:
+        td = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dt = float(td)
+    fl = (tr.engine.flops() + tr.engine.flops(backward=True)) * batch * accum
+    out = {'workload': f'configs[4]: halfcheetah diffusion training step, global micro-batch {batch} x {accum} accumulations per '
+                       f'optimiser step, data-parallel x{world} ({Bl} samples per rank and micro-batch)',
+           'samples_per_s': batch * accum / dt, 'ms_per_optimiser_step': 1e3 * dt, 'achieved': fl / dt / 1e12,
+           'peak': PEAK_F32_MFMA_TFLOPS * world, 'unit': 'TFLOP/s', 'frac': fl / dt / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+           'algorithmic_mflop_per_sample': {'forward': tr.engine.flops() / 1e6, 'backward': tr.engine.flops(backward=True) / 1e6},
+           'loss': float(losses[-1][0]), 'scaling': 'strong', 'dtype': 'f32'}
+    if cpu and rank == 0 and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import trebi_train_oracle as TO
+        Bc = 256
+        sdc = {k: v.copy() for k, v in sd.items()}
+        ema = {k: v.copy() for k, v in sd.items()}
+        opt = TO.Adam(lr=2e-4)
+        rng = np.random.default_rng(0)
+        times = []
+        for step in range(3):
+            bs = []
+            for _ in range(accum):
+                x = rng.standard_normal((Bc, H, D)).astype(np.float32)
+                bs.append((x, {0: x[:, 0, ACT:].copy()}, rng.integers(0, T, size=Bc), rng.standard_normal((Bc, H, D)).astype(np.float32)))
+            t0 = time.perf_counter()
+            TO.train_step(sdc, ema, opt, bs, H, OBS, ACT, T, step)
+            times.append(time.perf_counter() - t0)
+        try:
+            from threadpoolctl import threadpool_info
+            cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+        except Exception:
+            cores = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
+        out['cpu_baseline'] = {'value': Bc * accum / sorted(times)[1], 'unit': 'samples/s', 'cores': int(cores), 'kind': 'port',
+                               'sample': f'3 optimiser steps of {accum} x {Bc} samples through oracle/trebi_train_oracle.py '
+                                         '(numpy/OpenBLAS), median'}
+    del tr, diff
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(sds, B, thr, runs=5, big=512):
+    """The numpy oracle (a port of the reference path, oracle/trebi_oracle.py) on this box's host cores: the same workload
+    (B candidates, full 20-step constrained loop), median of `runs` calls, plus ONE call at `big` candidates
+    (the CPU path amortises its per-op overhead there); bounded to about half a minute of CPU work."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import trebi_oracle as O
     try:
@@ -138,19 +236,49 @@ def cpu_baseline(sds, B, thr, runs=2):
     c = O.ValueFunction(sds[2], H, D, DIM, MULTS)
     diff = O.GaussianDiffusion(u, H, OBS, ACT, T)
     rng = np.random.default_rng(0)
-    cond = {0: np.repeat(rng.standard_normal((1, OBS)).astype(np.float32), B, 0)}
-    best = None
-    for _ in range(runs):
-        noise = rng.standard_normal((T + 1, B, H, D)).astype(np.float32)
+
+    def call(n):
+        cond = {0: np.repeat(rng.standard_normal((1, OBS)).astype(np.float32), n, 0)}
+        noise = rng.standard_normal((T + 1, n, H, D)).astype(np.float32)
         t0 = time.perf_counter()
-        diff.p_sample_loop((B, H, D), cond, noise, O.n_step_guided_and_constrained_p_sample,
+        diff.p_sample_loop((n, H, D), cond, noise, O.n_step_guided_and_constrained_p_sample,
                            guide=O.ValueGuide(r), cost_guide=O.ValueGuide(c),
-                           cost_threshold=np.full(B, thr, np.float32), **PLAN_KW)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return dict(value=B / best, unit='trajectories/s', cores=int(cores), kind='port',
-                sample=f'{runs} full planning calls of the same workload ({B} candidates, H={H}, {T} steps, '
-                       f'reward+cost guide) through oracle/trebi_oracle.py (numpy/OpenBLAS), best of {runs}')
+                           cost_threshold=np.full(n, thr, np.float32), **PLAN_KW)
+        return time.perf_counter() - t0
+    times = sorted(call(B) for _ in range(runs))
+    med = times[len(times) // 2]
+    out = dict(value=B / med, unit='trajectories/s', cores=int(cores), kind='port',
+               sample=f'{runs} full planning calls of the same workload ({B} candidates, H={H}, {T} steps, '
+                      f'reward+cost guide) through oracle/trebi_oracle.py (numpy/OpenBLAS), median')
+    if big:
+        out['at_larger_batch'] = {'candidates': big, 'value': big / call(big), 'unit': 'trajectories/s', 'sample': 'one call'}
+    return out
+
+
+def variants(diff, planner, obs, n_global, guide, cguide, thr, device, world, steps=10):
+    """SURVEY.md 8d config 2's other two runs on the headline shapes: n_guide_steps = 1, and the budget
+    730.746 * ratio_of_maxthreshold (cost.py:32; with random-init nets every candidate is feasible there: the unpenalised
+    branch only).  Reported next to the headline, never as `value`."""
+    from diffuser.sampling import n_step_guided_and_constrained_p_sample as fn
+    out = []
+    for label, kw, th in (('n_guide_steps=1', dict(PLAN_KW, n_guide_steps=1), thr),
+                          ('cost_threshold = 730.746 * 0.5 (MAX_COST_DISCOUNT_THRESHOLD x ratio_of_maxthreshold)', dict(PLAN_KW),
+                           730.746 * 0.5)):
+        run = lambda: planner.plan(obs, n_global, H, fn, cost_threshold=th, guide=guide, cost_guide=cguide, copy=False, **kw)
+        for _ in range(2):
+            run()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / steps
+        out.append({'variant': label, 'trajectories_per_s': n_global / dt, 'ms_per_step': 1e3 * dt})
+    return out
 
 
 def main():
@@ -163,6 +291,7 @@ def main():
     ap.add_argument('--guide-steps', type=int, default=PLAN_KW['n_guide_steps'],
                     help='n_guide_steps (headline 2; SURVEY 8d also asks for 1)')
     ap.add_argument('--no-unet-util', action='store_true', help='skip the large-batch UNet utilisation measurement')
+    ap.add_argument('--no-train', action='store_true', help='skip the training-step extra (BASELINE configs[4])')
     ap.add_argument('--skip-dead-evals', action='store_true',
                     help='also drop guide evaluations whose result cannot reach an output (not the default)')
     args = ap.parse_args()
@@ -215,7 +344,7 @@ def main():
     kw = dict(PLAN_KW, guide=guide, cost_guide=cguide, skip_dead_evals=args.skip_dead_evals)
 
     def step():
-        return planner.plan(obs, n_global, H, fn, cost_threshold=thr, **kw)
+        return planner.plan(obs, n_global, H, fn, cost_threshold=thr, copy=False, **kw)
 
     def fence():
         if world > 1:
@@ -243,6 +372,11 @@ def main():
                     profile=True, **kw)
     torch.cuda.synchronize(device)
     prof = diff.last_profile
+
+    var = None if args.no_unet_util else variants(diff, planner, obs, n_global, guide, cguide, thr, device, world)
+    train = None if args.no_train else train_step_extra(device, world, rank, cpu=not args.no_cpu_baseline)
+    # configs[2] / configs[3]: per-GPU sizes on one GPU; sharded at their global sizes under world > 1 (strong scaling)
+    others = None if args.no_unet_util else other_configs(device, world=world, rank=rank, rehearse=rehearse)
 
     if rank == 0:
         F_unet = diff.model.flops()
@@ -285,7 +419,12 @@ def main():
         }
         if world == 1 and not args.no_unet_util:
             out['unet_mfma'] = unet_utilisation(diff.model, device)
-            out['other_configs'] = other_configs(device)
+        if others is not None:
+            out['other_configs'] = others
+        if var is not None:
+            out['variants'] = var
+        if train is not None:
+            out['train_step'] = train
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sds, B, thr)
         print(json.dumps(out), flush=True)

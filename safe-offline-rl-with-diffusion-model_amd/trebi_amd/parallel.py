@@ -25,12 +25,20 @@ def shard_bounds(n_global, world_size, rank):
 
 
 class ShardedPlanner:
-    def __init__(self, diffusion, group=None, local_fn=None, rule_fn=None, argsort_fn=None):
+    def __init__(self, diffusion, group=None, local_fn=None, rule_fn=None, argsort_fn=None, fence=None):
         """`local_fn(shape, cond, noise=..., **kw) -> (x, values_raw, costs)` defaults to the fused HIP loop;
         `rule_fn` / `argsort_fn` default to the library's selection kernels.  The hooks exist so the
         sharding logic can be exercised on CPU ranks (gloo) where there is no GPU."""
         self.diffusion = diffusion
         self.group = group
+        self._bufs = {}
+        # how the exchange is ordered behind the captured loop: 'host' = drain the launch stream (default for gloo and
+        # whenever TREBI_PLAN_SYNC=1), 'stream' = leave it to the backend's own event wait (default for RCCL)
+        if fence is None:
+            env = os.environ.get('TREBI_PLAN_SYNC')
+            backend = dist.get_backend(group) if dist.is_available() and dist.is_initialized() else 'none'
+            fence = 'host' if (env == '1' or (env is None and backend != 'nccl')) else 'stream'
+        self.fence = fence
         if local_fn is None:
             def local_fn(shape, cond, noise=None, **kw):
                 x, v, c, _ = diffusion.sample_raw(shape, cond, noise=noise, **kw)
@@ -46,27 +54,26 @@ class ShardedPlanner:
             return dist.get_world_size(self.group), dist.get_rank(self.group)
         return 1, 0
 
-    def _all_gather_ragged(self, t, sizes):
-        """all_gather of 1-D tensors whose length differs by at most one across ranks (pad to the max)."""
-        world, _ = self._world()
-        if world == 1:
-            return t
-        m = max(sizes)
-        pad = torch.zeros(m, dtype=t.dtype, device=t.device)
-        pad[:t.numel()] = t
-        outs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(outs, pad, group=self.group)
-        return torch.cat([o[:n] for o, n in zip(outs, sizes)])
+    def _buffers(self, world, m, like):
+        """Exchange buffers, allocated once per (world, shard size, device): send [2, m] = (values | costs) padded to
+        the largest shard, receive [world, 2, m]."""
+        key = (world, m, str(like.device), like.dtype)
+        if self._bufs.get('key') != key:
+            self._bufs = dict(key=key, send=torch.zeros(2, m, dtype=like.dtype, device=like.device),
+                              recv=torch.empty(world, 2, m, dtype=like.dtype, device=like.device))
+        return self._bufs['send'], self._bufs['recv']
 
     @torch.no_grad()
     def plan(self, observation, n_candidates, horizon, sample_fn, cost_threshold=None, noise=None,
-             constrained=True, **sample_kwargs):
+             constrained=True, copy=True, **sample_kwargs):
         """observation: [obs_dim] normalised observation shared by all candidates (policies.py:77-82);
-        noise: optional GLOBAL [T+1, n_candidates, H, D] tensor (each rank takes its slice)."""
+        noise: optional GLOBAL [T+1, n_candidates, H, D] tensor (each rank takes its slice).
+        copy=False returns views of the sampler's persistent buffers in `local_trajectories` / `costs` (the next
+        plan() overwrites them; the reference returns fresh tensors, which is what the default does)."""
         world, rank = self._world()
-        lo, hi = shard_bounds(n_candidates, world, rank)
-        sizes = [shard_bounds(n_candidates, world, r)[1] - shard_bounds(n_candidates, world, r)[0]
-                 for r in range(world)]
+        bounds = [shard_bounds(n_candidates, world, r) for r in range(world)]
+        sizes = [hi - lo for lo, hi in bounds]
+        lo, hi = bounds[rank]
         B = hi - lo
         D = self.diffusion.transition_dim
         obs = torch.as_tensor(observation, dtype=torch.float32)
@@ -77,34 +84,36 @@ class ShardedPlanner:
             kw['cost_threshold'] = thr if thr.dim() == 0 else thr[lo:hi]
         nz = None if noise is None else noise[:, lo:hi]
         x, v_raw, c = self.local_fn((B, horizon, D), cond, noise=nz, sample_fn=sample_fn, **kw)
-        # ---- the one exchange: per-candidate scores ----
-        packed = torch.cat([v_raw.reshape(-1), c.reshape(-1)])
+        # ---- the one exchange: per-candidate scores, ONE all-gather of (values | costs) ----
         if world > 1:
             m = max(sizes)
-            pad = torch.zeros(2 * m, dtype=packed.dtype, device=packed.device)
-            pad[:B] = v_raw.reshape(-1)
-            pad[m:m + B] = c.reshape(-1)
-            if pad.is_cuda and os.environ.get('TREBI_PLAN_SYNC', '1') == '1':
-                # the scores are needed on the host right after the exchange anyway; draining the launch stream first
-                # keeps the backend's side stream from queueing behind the captured loop (two ranks sharing one GPU
-                # over gloo stalled there; see tools/rehearse_ranks.py)
-                torch.cuda.current_stream(pad.device).synchronize()
-            outs = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(outs, pad, group=self.group)          # single fused all-gather (values | costs)
-            v_all = torch.cat([o[:n] for o, n in zip(outs, sizes)])
-            c_all = torch.cat([o[m:m + n] for o, n in zip(outs, sizes)])
+            send, recv = self._buffers(world, m, v_raw)
+            send[0, :B].copy_(v_raw.reshape(-1))
+            send[1, :B].copy_(c.reshape(-1))
+            if send.is_cuda and self.fence == 'host':
+                # drain the launch stream first (free: the scores are read on the host right after the exchange).
+                # Needed with gloo, whose device-tensor path stages through the host; RCCL enqueues its kernel on a
+                # stream that waits for the current stream through an event (fence 'stream': nothing to do here).
+                torch.cuda.current_stream(send.device).synchronize()
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+            if min(sizes) == m:
+                v_all, c_all = recv[:, 0, :].reshape(-1), recv[:, 1, :].reshape(-1)
+            else:
+                v_all = torch.cat([recv[r, 0, :n] for r, n in enumerate(sizes)])
+                c_all = torch.cat([recv[r, 1, :n] for r, n in enumerate(sizes)])
         else:
             v_all, c_all = v_raw.reshape(-1), c.reshape(-1)
+            if copy:
+                v_all, c_all = v_all.clone(), c_all.clone()
         if constrained:
             thr = torch.as_tensor(cost_threshold, dtype=torch.float32, device=v_all.device)
             thr_all = thr.expand(n_candidates) if thr.dim() == 0 else thr
             v_all = self.rule_fn(v_all, c_all, thr_all)
         order = self.argsort_fn(v_all)
         best = int(order[0])
-        owner = next(r for r in range(world) if shard_bounds(n_candidates, world, r)[0] <= best
-                     < shard_bounds(n_candidates, world, r)[1])
+        owner = next(r for r, (a, b) in enumerate(bounds) if a <= best < b)
         traj = x[best - lo].clone() if rank == owner else torch.empty(horizon, D, dtype=x.dtype, device=x.device)
         if world > 1:
             src = dist.get_global_rank(self.group, owner) if self.group is not None else owner
             dist.broadcast(traj, src=src, group=self.group)
-        return Plan(best, traj, v_all, c_all, order, x, (lo, hi))
+        return Plan(best, traj, v_all, c_all, order, x.clone() if copy else x, (lo, hi))

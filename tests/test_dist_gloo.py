@@ -60,23 +60,125 @@ def _worker(rank, world, port, n, thr, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n,thr', [(13, 1.1), (64, 0.9), (64, -5.0)])
-def test_two_ranks_equal_one(n, thr):
+@pytest.mark.parametrize('n,thr,world', [(13, 1.1, 2), (64, 0.9, 2), (64, -5.0, 2), (4096, 0.9, 3), (7, 1.1, 3)])
+def test_ranks_equal_one(n, thr, world):
+    """2 ranks, and the ragged 3-rank split of configs[2]'s 4096 candidates (1366 / 1365 / 1365)."""
     ref = _plan(n, thr)                      # world size 1, whole batch
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + n) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, thr, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + n + world) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, thr, q)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=120) for _ in procs], key=lambda o: o[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert outs[0][6][1] == outs[1][6][0] and outs[0][6][0] == 0 and outs[1][6][1] == n
+    assert outs[0][6][0] == 0 and outs[-1][6][1] == n
+    assert all(a[6][1] == b[6][0] for a, b in zip(outs[:-1], outs[1:]))
     for rank, best, traj, v, c, order, _ in outs:
         assert best == ref.best_index
-        np.testing.assert_array_equal(traj, ref.best_trajectory.numpy())
-        np.testing.assert_array_equal(v, ref.values.numpy())
-        np.testing.assert_array_equal(c, ref.costs.numpy())
+        np.testing.assert_allclose(traj, ref.best_trajectory.numpy(), rtol=1e-6, atol=1e-7)
+        if n <= 64 and world == 2:
+            np.testing.assert_array_equal(v, ref.values.numpy())
+            np.testing.assert_array_equal(c, ref.costs.numpy())
+        else:       # the torch CPU stand-in itself rounds differently at other shard sizes (1 ulp): not the exchange
+            np.testing.assert_allclose(v, ref.values.numpy(), rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(c, ref.costs.numpy(), rtol=1e-6, atol=1e-7)
         np.testing.assert_array_equal(order, ref.order.numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# data-parallel TRAINING step (SURVEY.md 8f rank 1): every rank accumulates its shard's gradient, ONE all-reduce of
+# the flat gradient, then the same optimiser step everywhere.  The per-rank gradient computation is replaced by the
+# numpy training oracle (test infrastructure) -- what is under test is trebi_amd.training.Trainer's scaling
+# (B_local / B_global per micro-batch, 1 / accumulation steps), the collective and the step bookkeeping.
+# ---------------------------------------------------------------------------------------------------------
+H_, OBS_, ACT_, T_, DIM_, MULTS_ = 8, 3, 1, 20, 32, (1, 2)
+
+
+class _OracleEngine:
+    def __init__(self, diffusion, max_batch):
+        sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'oracle'))
+        import trebi_oracle as O
+        import trebi_train_oracle as TO
+        from trebi_amd import spec, synth
+        self.O, self.TO = O, TO
+        self.sd = synth.synth_state_dict(spec.unet_param_shapes(H_, OBS_ + ACT_, DIM_, MULTS_), 77)
+        self.names = list(self.sd.keys())
+        self.grads = torch.zeros(sum(v.size for v in self.sd.values()))
+        self.lw = TO.loss_weights(H_, OBS_ + ACT_, ACT_, 10.0)
+        self.sched = O.make_schedule(T_)
+        self.steps = []
+
+    def accumulate(self, x, cond, t, noise, grad_scale=1.0):
+        unet = self.TO.TrainableUnet(self.sd, H_, OBS_ + ACT_, DIM_, MULTS_)
+        loss, a0, g = self.TO.p_losses(unet, x.numpy(), {0: cond[0].numpy()}, t.numpy(), noise.numpy(), self.lw, ACT_,
+                                       self.sched)
+        flat = np.concatenate([g[k].reshape(-1) for k in self.names])
+        self.grads += grad_scale * torch.from_numpy(flat)
+        return torch.tensor([loss, a0])
+
+    def step(self, adam_step, lr, betas, eps, ema_mode, ema_decay):
+        self.steps.append((adam_step, ema_mode, self.grads.clone()))
+        self.grads.zero_()
+
+
+def _train_batches(n):
+    from trebi_amd import synth
+    out = []
+    for i in range(2):
+        x = synth.synth_normal(3, f'dp.x{i}', (n, H_, OBS_ + ACT_))
+        c = synth.synth_normal(3, f'dp.c{i}', (n, OBS_))
+        x[:, 0, ACT_:] = c
+        t = np.random.default_rng(i).integers(0, T_, size=n)
+        nz = synth.synth_normal(3, f'dp.n{i}', (n, H_, OBS_ + ACT_))
+        out.append(tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in (x, c, t, nz)))
+    return out
+
+
+class _Model:
+    n_timesteps = T_
+
+
+def _train(n, world, rank):
+    from trebi_amd.parallel import shard_bounds
+    from trebi_amd.training import Trainer
+    tr = Trainer(_Model(), train_batch_size=n, train_lr=2e-4, gradient_accumulate_every=2, step_start_ema=1,
+                 update_ema_every=1, engine_factory=_OracleEngine, distributed=world > 1)
+    lo, hi = shard_bounds(n, world, rank)
+    batches = [(x[lo:hi], {0: c[lo:hi]}, t[lo:hi], nz[lo:hi]) for x, c, t, nz in _train_batches(n)]
+    losses = tr.train_step(batches, global_batch_sizes=[n, n])
+    return tr.engine.steps[0], [l.numpy() for l in losses], tr.step
+
+
+def _train_worker(rank, world, port, n, q):
+    sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), 'safe-offline-rl-with-diffusion-model_amd')]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    (adam_step, ema_mode, g), losses, step = _train(n, world, rank)
+    q.put((rank, adam_step, ema_mode, g.numpy(), step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n', [6, 7])
+def test_data_parallel_gradients_equal_single_rank(n):
+    """All-reduced gradients of 2 ranks (even and ragged shards) == the single-rank gradient of the whole batch."""
+    (adam_step, ema_mode, ref), _, _ = _train(n, 1, 0)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + n) % 2000
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    scale = np.abs(ref.numpy()).max()
+    for rank, a, e, g, step in outs:
+        assert (a, e, step) == (adam_step, ema_mode, 1)
+        assert np.abs(g - ref.numpy()).max() <= 2e-6 * scale, rank      # float32 summation order only
+    np.testing.assert_array_equal(outs[0][3], outs[1][3])               # every rank steps with identical gradients
