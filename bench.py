@@ -255,6 +255,29 @@ def cpu_baseline(sds, B, thr, runs=5, big=512):
     return out
 
 
+def control_step_extra(diff, guide, cguide, thr, device, B, steps=20):
+    """whole control steps through GuidedPolicy (policies.py:25-63): raw observation in (numpy), normalise,
+    repeat, budget tensor, the captured loop, selection, un-normalised first action out (numpy) -- what the episode loop of
+    scripts/plan_cost_guided.py:208-210 calls once per environment step."""
+    from diffuser.sampling import GuidedPolicy, n_step_guided_and_constrained_p_sample as fn
+    from trebi_amd.policy import GaussianNormalizer
+    rng = np.random.default_rng(3)
+    norm = GaussianNormalizer({'observations': (rng.standard_normal(OBS), 0.5 + rng.random(OBS)),
+                               'actions': (rng.standard_normal(ACT), 0.5 + rng.random(ACT))})
+    policy = GuidedPolicy(guide, diff, norm, [], sample_fn=fn, cost_guide=cguide, cost_threshold=thr, **PLAN_KW)
+    obs = rng.standard_normal(OBS).astype(np.float32)
+    for _ in range(3):
+        policy({0: obs}, batch_size=B, verbose=False)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        action, _ = policy({0: obs + 0.01 * i}, batch_size=B, verbose=False, cost_threshold=thr * (1 + 0.001 * i))
+    dt = (time.perf_counter() - t0) / steps          # the action is on the host when the call returns
+    return {'workload': f'GuidedPolicy control step, {B} candidates (numpy observation in, numpy action out)',
+            'control_steps_per_s': 1.0 / dt, 'ms_per_control_step': 1e3 * dt,
+            'device_to_host_bytes_per_step': ACT * 4, 'host_to_device_bytes_per_step': (OBS + 1) * 4}
+
+
 def variants(diff, planner, obs, n_global, guide, cguide, thr, device, world, steps=10):
     """SURVEY.md 8d config 2's other two runs on the headline shapes: n_guide_steps = 1, and the budget
     730.746 * ratio_of_maxthreshold (cost.py:32; with random-init nets every candidate is feasible there: the unpenalised
@@ -373,6 +396,7 @@ def main():
     torch.cuda.synchronize(device)
     prof = diff.last_profile
 
+    ctl = control_step_extra(diff, guide, cguide, thr, device, B) if (rank == 0 and world == 1 and not args.no_unet_util) else None
     var = None if args.no_unet_util else variants(diff, planner, obs, n_global, guide, cguide, thr, device, world)
     train = None if args.no_train else train_step_extra(device, world, rank, cpu=not args.no_cpu_baseline)
     # configs[2] / configs[3]: per-GPU sizes on one GPU; sharded at their global sizes under world > 1 (strong scaling)
@@ -423,6 +447,8 @@ def main():
             out['other_configs'] = others
         if var is not None:
             out['variants'] = var
+        if ctl is not None:
+            out['control_step'] = ctl
         if train is not None:
             out['train_step'] = train
         if world == 1 and not args.no_cpu_baseline:

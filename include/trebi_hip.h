@@ -8,9 +8,10 @@
  * types only: device pointers are `float*` / `int64_t*` on the context's GPU,
  * streams are passed as `void*` (a hipStream_t).  Every call returns 0 on
  * success or a negative trebi_status; trebi_last_error() gives the message of the
- * last failure on the calling thread.  No call synchronises the device and,
- * except the *_create / *_destroy pairs, no call allocates: workspaces are
- * caller-owned (size from the *_workspace_bytes queries).
+ * last failure on the calling thread.  Only the set-up calls (*_create, *_bind,
+ * *_destroy) allocate or synchronise the device; every other call only enqueues on
+ * the stream it is given (a profiled trebi_sampler_run, a diagnostic, also creates
+ * timing events).  Workspaces are caller-owned (size from the *_workspace_bytes queries).
  *
  * Tensor conventions (all float32, contiguous unless a row stride is given):
  *   x, grad, trajectories : [B, horizon, ldx]   (ldx >= transition_dim; the nets read the
@@ -166,6 +167,25 @@ int trebi_argsort_desc(trebi_ctx* ctx, const float* values, int n, int64_t* orde
 int trebi_group_argmax(trebi_ctx* ctx, const float* values, int n_groups, int per,
                        int64_t* best_out, void* stream);
 
+/* ---- GuidedPolicy glue on the device ----------------------------------------------
+ * GuidedPolicy._format_conditions and the cost-threshold tensor
+ * (/root/reference/diffuser/sampling/policies.py:28-36,70-82):
+ *   cond_out[b, :] = (obs[b % n_obs, :] - mean) / std     (GaussianNormalizer.normalize,
+ *                    diffuser/datasets/normalization.py:145-146; mean == std == NULL: obs is already normalised;
+ *                    einops 'd w -> (repeat d) w': the repeat index is the outer one)
+ *   thr_out[b]     = thr[b % n_thr]                        (torch.tensor(thr).repeat(batch_size); thr_out NULL: skipped)
+ * obs: dev [n_obs, obs_dim] raw observations; B = batch_size * n_obs rows are written. */
+int trebi_policy_prepare(trebi_ctx* ctx, const float* obs, int n_obs, int obs_dim, const float* mean,
+                         const float* stdv, int B, float* cond_out, const float* thr, int n_thr, float* thr_out,
+                         void* stream);
+/* policies.py:38-47: action_out[i, :] = trajectories[index[i], 0, :action_dim] * std + mean
+ * (GaussianNormalizer.unnormalize, normalization.py:148-149; NULL statistics: left normalised) -- only what the
+ * caller reads leaves the device; x: dev [B, horizon, transition_dim], index: dev [n] (e.g. the head of
+ * trebi_argsort_desc's order, or trebi_group_argmax's result). */
+int trebi_policy_first_action(trebi_ctx* ctx, const float* x, int B, int horizon, int transition_dim, int action_dim,
+                              const int64_t* index, int n, const float* mean, const float* stdv, float* action_out,
+                              void* stream);
+
 /* ---- the whole reverse-diffusion loop ---------------------------------------------
  * GaussianDiffusion.p_sample_loop (diffusion.py:187-206) driving default_sample_fn
  * (diffusion.py:19-29), n_step_guided_p_sample (functions.py:9-37) or
@@ -193,7 +213,16 @@ void trebi_sampler_destroy(trebi_sampler* s);
 /* noise: dev [n_timesteps+1, B, horizon, transition_dim] (noise[0] is x_T, noise[1+k] the k-th step's
  * draw, diffusion.py:192 / functions.py:134); x_out: dev [B,horizon,transition_dim]; values/costs:
  * dev [B], the guides' raw outputs at the last step (zeros where the sample function has none);
- * chain: nullable dev [n_timesteps+1, B, horizon, transition_dim]. */
+ * chain: nullable dev [n_timesteps+1, B, horizon, transition_dim].
+ *
+ * trebi_sampler_bind is the set-up call for a set of buffers (like *_create it allocates and
+ * synchronises): it resolves every network pass to launches for these pointers and, with
+ * use_graph, captures and instantiates the loop.  trebi_sampler_run then only enqueues (one
+ * hipGraphLaunch, or the plain launches of the loop for use_graph = 0, which a caller may capture
+ * into its own graph); it refuses pointers other than the bound ones.  The CONTENTS of the
+ * buffers may change freely between runs. */
+int trebi_sampler_bind(trebi_sampler* s, const float* noise, const float* const* cond,
+                       const float* cost_threshold, float* x_out, float* values, float* costs, float* chain);
 int trebi_sampler_run(trebi_sampler* s, const float* noise, const float* const* cond,
                       const float* cost_threshold /* dev [B], nullable unless kind 2 */,
                       float* x_out, float* values, float* costs, float* chain, void* stream);

@@ -160,6 +160,10 @@ hipError_t launch_ddpm_update(const StepP& s, float* x, const float* x0, const f
                               const float* c2, int B, float* chain_out, hipStream_t st);
 hipError_t launch_init_x(const StepP& s, float* x, const float* noise0, int B, float* chain_out,
                          hipStream_t st);
+hipError_t launch_policy_prepare(const float* obs, int n_obs, int obs_dim, const float* mean, const float* stdv, int B,
+                                 float* cond, const float* thr, int n_thr, float* thr_out, hipStream_t st);
+hipError_t launch_policy_action(const float* x, int H, int D, int act, const long long* index, int n, int B,
+                                const float* mean, const float* stdv, float* out, hipStream_t st);
 hipError_t launch_fill_t(long long* t, int B, int value, hipStream_t st);
 hipError_t launch_fill_f(float* p, int n, float value, hipStream_t st);
 hipError_t launch_feasibility(const float* ry, const float* cy, const float* thr, int n, float* out,

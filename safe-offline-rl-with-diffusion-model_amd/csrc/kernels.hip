@@ -229,6 +229,51 @@ hipError_t launch_init_x(const StepP& s, float* x, const float* noise0, int B, f
   return hipGetLastError();
 }
 
+// ----------------------------------------------------------------------------------
+// GuidedPolicy glue (policies.py:25-45, 70-82) on the device
+// ----------------------------------------------------------------------------------
+// _format_conditions + the threshold tensor: cond[b, :] = normalize(obs[b % n_obs, :]) (einops 'd w -> (repeat d) w':
+// the repeat index is the OUTER one), thr_out[b] = thr[b % n_thr] (torch.tensor(thr).repeat(batch_size)).
+// GaussianNormalizer.normalize (normalization.py:145-146): (x - mean) / std; mean == null: obs is already normalised.
+__global__ void policy_prepare_kernel(const float* obs, int n_obs, int obs_dim, const float* mean, const float* stdv, int B,
+                                      float* cond, const float* thr, int n_thr, float* thr_out) {
+  const int total = B * obs_dim;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / obs_dim, d = i - b * obs_dim;
+    float v = obs[(b % n_obs) * obs_dim + d];
+    if (mean) v = (v - mean[d]) / stdv[d];
+    cond[i] = v;
+  }
+  if (thr_out)
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) thr_out[b] = thr[b % n_thr];
+}
+hipError_t launch_policy_prepare(const float* obs, int n_obs, int obs_dim, const float* mean, const float* stdv, int B,
+                                 float* cond, const float* thr, int n_thr, float* thr_out, hipStream_t st) {
+  int blocks = (B * obs_dim + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(policy_prepare_kernel, dim3(blocks), dim3(256), 0, st, obs, n_obs, obs_dim, mean, stdv, B, cond, thr,
+                     n_thr, thr_out);
+  return hipGetLastError();
+}
+// action = unnormalize(trajectories[index[i], 0, :action_dim]) (policies.py:41-47; normalization.py:148-149: x*std + mean)
+__global__ void policy_action_kernel(const float* x, int H, int D, int act, const long long* index, int n, int B,
+                                     const float* mean, const float* stdv, float* out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * act; i += gridDim.x * blockDim.x) {
+    const int k = i / act, d = i - k * act;
+    long long b = index[k];
+    b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+    float v = x[(size_t)b * H * D + d];
+    if (mean) v = v * stdv[d] + mean[d];
+    out[i] = v;
+  }
+}
+hipError_t launch_policy_action(const float* x, int H, int D, int act, const long long* index, int n, int B,
+                                const float* mean, const float* stdv, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(policy_action_kernel, dim3((n * act + 63) / 64), dim3(64), 0, st, x, H, D, act, index, n, B, mean, stdv,
+                     out);
+  return hipGetLastError();
+}
+
 __global__ void fill_t_kernel(long long* t, int B, int value) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) t[i] = value;
 }

@@ -1815,6 +1815,30 @@ extern "C" int trebi_group_argmax(trebi_ctx* ctx, const float* values, int n_gro
 }
 
 // ------------------------------------------------------------------------------------
+// GuidedPolicy glue on the device (policies.py:25-45, 70-82)
+// ------------------------------------------------------------------------------------
+extern "C" int trebi_policy_prepare(trebi_ctx* ctx, const float* obs, int n_obs, int obs_dim, const float* mean,
+                                    const float* stdv, int B, float* cond_out, const float* thr, int n_thr, float* thr_out,
+                                    void* stream) {
+  if (!ctx || !obs || !cond_out || n_obs < 1 || obs_dim < 1 || B < 1) return fail(TREBI_BAD_ARG, "null argument");
+  if ((mean == nullptr) != (stdv == nullptr)) return fail(TREBI_BAD_ARG, "mean and std go together");
+  if (B % n_obs) return fail(TREBI_BAD_SHAPE, "batch %d is not a multiple of the %d observations", B, n_obs);
+  if (thr_out && (!thr || n_thr < 1 || B % n_thr)) return fail(TREBI_BAD_SHAPE, "threshold list does not tile the batch");
+  HIPCHK(launch_policy_prepare(obs, n_obs, obs_dim, mean, stdv, B, cond_out, thr, n_thr, thr_out, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int trebi_policy_first_action(trebi_ctx* ctx, const float* x, int B, int horizon, int transition_dim,
+                                         int action_dim, const int64_t* index, int n, const float* mean, const float* stdv,
+                                         float* action_out, void* stream) {
+  if (!ctx || !x || !index || !action_out || n < 1 || B < 1) return fail(TREBI_BAD_ARG, "null argument");
+  if ((mean == nullptr) != (stdv == nullptr)) return fail(TREBI_BAD_ARG, "mean and std go together");
+  if (action_dim < 1 || action_dim > transition_dim || horizon < 1) return fail(TREBI_BAD_SHAPE, "inconsistent dimensions");
+  HIPCHK(launch_policy_action(x, horizon, transition_dim, action_dim, (const long long*)index, n, B, mean, stdv, action_out,
+                              (hipStream_t)stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // the captured sampling loop
 // ------------------------------------------------------------------------------------
 struct trebi_sampler {
@@ -1841,6 +1865,7 @@ struct trebi_sampler {
   size_t dev_tab_cap = 0;
   const void* plan_key[3] = {};
   bool plans_valid = false;
+  bool bound = false;               // trebi_sampler_bind succeeded for the pointers in `key`
   ~trebi_sampler() {
     if (dev_tab) (void)hipFree(dev_tab);
     if (exec) (void)hipGraphExecDestroy(exec);
@@ -2011,15 +2036,52 @@ static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const
   return 0;
 }
 
-extern "C" int trebi_sampler_run(trebi_sampler* s, const float* noise, const float* const* cond, const float* thr,
-                                 float* x, float* values, float* costs, float* chain, void* stream) {
+// Set-up for a set of caller buffers: resolves every network pass to launches for these pointers (allocates the
+// device table of chained stages, synchronises) and, for a graph sampler, captures + instantiates the loop.
+extern "C" int trebi_sampler_bind(trebi_sampler* s, const float* noise, const float* const* cond, const float* thr,
+                                  float* x, float* values, float* costs, float* chain) {
   if (!s || !noise || !x || !values || !costs) return fail(TREBI_BAD_ARG, "null argument");
   if (s->d.kind == 2 && !thr) return fail(TREBI_BAD_ARG, "constrained sampling needs cost_threshold");
   if (s->d.step.n_cond > 0 && !cond) return fail(TREBI_BAD_ARG, "cond is null");
-  hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(s->ctx->device));
+  s->bound = false;
   if (int e = ensure_plans(s, x, values, costs)) return e;
-  if (s->prof.enabled) {          // profiled run: plain launches bracketed by events
+  const void* key[12] = {noise, thr, x, values, costs, chain};
+  for (int k = 0; k < s->d.step.n_cond; ++k) key[6 + k] = cond[k];
+  if (s->d.use_graph && (!s->exec || memcmp(key, s->key, sizeof key) != 0)) {
+    if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+    hipStream_t cap;
+    HIPCHK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    hipError_t e0 = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+    int rc = 0;
+    if (e0 == hipSuccess) rc = enqueue_loop(s, noise, cond, thr, x, values, costs, chain, cap, nullptr);
+    hipError_t e1 = e0 == hipSuccess ? hipStreamEndCapture(cap, &graph) : e0;
+    (void)hipStreamDestroy(cap);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e1 != hipSuccess) return fail(TREBI_HIP_ERROR, "graph capture failed: %s", hipGetErrorString(e1));
+    hipError_t e2 = hipGraphInstantiate(&s->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) { s->exec = nullptr; return fail(TREBI_HIP_ERROR, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
+  }
+  memcpy(s->key, key, sizeof key);
+  s->bound = true;
+  return 0;
+}
+
+// Only enqueues (one hipGraphLaunch, or the loop's plain launches for use_graph = 0): no allocation, no
+// synchronisation -- a use_graph = 0 sampler can be captured into the caller's own graph.
+extern "C" int trebi_sampler_run(trebi_sampler* s, const float* noise, const float* const* cond, const float* thr,
+                                 float* x, float* values, float* costs, float* chain, void* stream) {
+  if (!s || !noise || !x || !values || !costs) return fail(TREBI_BAD_ARG, "null argument");
+  if (s->d.step.n_cond > 0 && !cond) return fail(TREBI_BAD_ARG, "cond is null");
+  const void* key[12] = {noise, thr, x, values, costs, chain};
+  for (int k = 0; k < s->d.step.n_cond; ++k) key[6 + k] = cond[k];
+  if (!s->bound || memcmp(key, s->key, sizeof key) != 0)
+    return fail(TREBI_BAD_ARG, "the sampler is not bound to these buffers: call trebi_sampler_bind first "
+                "(it resolves the launch plans and captures the loop for a given set of pointers)");
+  hipStream_t st = (hipStream_t)stream;
+  if (s->prof.enabled) {          // profiled run (diagnostics; creates timing events): plain launches bracketed by events
     s->prof.reset();
     HIPCHK(hipEventRecord(s->ev_a, st));
     if (int e = enqueue_loop(s, noise, cond, thr, x, values, costs, chain, st, &s->prof)) return e;
@@ -2039,25 +2101,6 @@ extern "C" int trebi_sampler_run(trebi_sampler* s, const float* noise, const flo
     return 0;
   }
   if (!s->d.use_graph) return enqueue_loop(s, noise, cond, thr, x, values, costs, chain, st, nullptr);
-  const void* key[12] = {noise, thr, x, values, costs, chain, st};
-  for (int k = 0; k < s->d.step.n_cond; ++k) key[7 + k] = cond[k];
-  if (!s->exec || memcmp(key, s->key, sizeof key) != 0) {
-    if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
-    hipStream_t cap;
-    HIPCHK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-    hipGraph_t graph = nullptr;
-    hipError_t e0 = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-    int rc = 0;
-    if (e0 == hipSuccess) rc = enqueue_loop(s, noise, cond, thr, x, values, costs, chain, cap, nullptr);
-    hipError_t e1 = e0 == hipSuccess ? hipStreamEndCapture(cap, &graph) : e0;
-    (void)hipStreamDestroy(cap);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (e1 != hipSuccess) return fail(TREBI_HIP_ERROR, "graph capture failed: %s", hipGetErrorString(e1));
-    hipError_t e2 = hipGraphInstantiate(&s->exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e2 != hipSuccess) { s->exec = nullptr; return fail(TREBI_HIP_ERROR, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
-    memcpy(s->key, key, sizeof key);
-  }
   HIPCHK(hipGraphLaunch(s->exec, st));
   return 0;
 }

@@ -63,9 +63,13 @@ SIGNATURES = {
     'trebi_feasibility_rule': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP]),
     'trebi_argsort_desc': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     'trebi_group_argmax': (C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, _VP]),
+    'trebi_policy_prepare': (C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, _VP, C.c_int, _VP, _VP, C.c_int, _VP, _VP]),
+    'trebi_policy_first_action': (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int, _VP, _VP, _VP,
+                                            _VP]),
     'trebi_sampler_create': (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(SamplerDesc), c_float_p, c_float_p,
                                        c_float_p, C.c_int, C.POINTER(_VP)]),
     'trebi_sampler_destroy': (None, [_VP]),
+    'trebi_sampler_bind': (C.c_int, [_VP, _VP, C.POINTER(_VP), _VP, _VP, _VP, _VP, _VP]),
     'trebi_sampler_run': (C.c_int, [_VP, _VP, C.POINTER(_VP), _VP, _VP, _VP, _VP, _VP, _VP]),
     'trebi_sampler_set_profiling': (C.c_int, [_VP, C.c_int]),
     'trebi_sampler_get_profile': (C.c_int, [_VP, C.POINTER(C.c_double), c_i64_p, C.POINTER(C.c_double),

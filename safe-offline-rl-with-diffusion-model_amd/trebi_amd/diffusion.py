@@ -436,9 +436,13 @@ class GaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def sample_raw(self, shape, cond, sample_fn=default_sample_fn, return_chain=False, noise=None,
-                   use_graph=True, skip_dead_evals=False, profile=False, **sample_kwargs):
+                   use_graph=True, skip_dead_evals=False, profile=False, prepared=False, **sample_kwargs):
         """The fused loop without the final selection: returns (x[B,H,D], values_raw[B], costs[B],
-        chain|None) for this rank's candidates.  ShardedPlanner all-gathers values/costs."""
+        chain|None) for this rank's candidates.  ShardedPlanner all-gathers values/costs.
+        The returned tensors are the sampler's persistent buffers: the next call with the same batch size and
+        arguments overwrites them (clone what must outlive it).  prepared=True: the caller has already filled the
+        sampler's cond / threshold buffers on the device (GuidedPolicy does, with trebi_policy_prepare); `cond` then
+        only names the conditioned timesteps."""
         if self.predict_epsilon or self.clip_denoised:
             raise RuntimeError('the fused loop computes x0-parameterised, unclipped steps only (predict_epsilon=False, '
                                'clip_denoised=False, config/locomotion.py:30,39); use p_sample_loop, which runs such '
@@ -456,14 +460,22 @@ class GaussianDiffusion(nn.Module):
             s['noise'].normal_()                    # one generator call instead of T+1 (diffusion.py:192, functions.py:134)
         else:
             s['noise'].copy_(torch.as_tensor(noise, device=device).reshape(s['noise'].shape))
-        for buf, v in zip(s['cond'], _cond_tensors(cond, keys, B, self.observation_dim, device)):
-            buf.copy_(v)
-        if kind == 2:
-            thr = sample_kwargs.get('cost_threshold', 0)
-            s['thr'].copy_(torch.as_tensor(thr, device=device, dtype=torch.float32).expand(B))
+        if not prepared:
+            for buf, v in zip(s['cond'], _cond_tensors(cond, keys, B, self.observation_dim, device)):
+                buf.copy_(v)
+            if kind == 2:
+                thr = sample_kwargs.get('cost_threshold', 0)
+                s['thr'].copy_(torch.as_tensor(thr, device=device, dtype=torch.float32).expand(B))
         if return_chain and s['chain'] is None:
             s['chain'] = torch.empty(self.n_timesteps + 1, B, H, D, device=device)
         chain = s['chain'] if return_chain else None
+        bound = (s['noise'].data_ptr(), None if chain is None else chain.data_ptr())
+        if s.get('bound') != bound:                 # set-up for this set of buffers: launch plans + graph capture
+            with torch.cuda.device(device):
+                _lib.check(_lib.lib().trebi_sampler_bind(s['h'], _lib.ptr(s['noise']), _lib.ptr_array(s['cond']),
+                                                         _lib.ptr(s['thr']), _lib.ptr(s['x']), _lib.ptr(s['values']),
+                                                         _lib.ptr(s['costs']), _lib.ptr(chain)))
+            s['bound'] = bound
         if profile:
             _lib.check(_lib.lib().trebi_sampler_set_profiling(s['h'], 1))
         _lib.check(_lib.lib().trebi_sampler_run(s['h'], _lib.ptr(s['noise']), _lib.ptr_array(s['cond']),

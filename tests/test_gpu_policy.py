@@ -79,3 +79,62 @@ def test_batched_observations_pick_per_group_maximum(setup):
     sel = x.reshape(n_obs, rep, H, -1)[torch.arange(n_obs), best]
     assert rel_err(traj.actions, norm.unnormalize(sel[:, :, :act].cpu().numpy(), 'actions')) < 1e-6
     assert torch.equal(traj.values, v.reshape(n_obs, rep).max(dim=1).values)
+
+
+def test_one_control_step_moves_under_1kb_to_the_host(setup, monkeypatch):
+    """at 8192 candidates the reference copies 24 MB to the host per control step to read one
+    action; here only the action leaves the device unless the caller reads the plans.  Every device->host route a
+    torch tensor has is counted."""
+    from diffuser.sampling import GuidedPolicy, n_step_guided_and_constrained_p_sample as fn
+    fx, diff, guide, cguide, norm = setup
+    act, obs = int(fx['act']), int(fx['obs'])
+    B = 8192
+    policy = GuidedPolicy(guide, diff, norm, [], sample_fn=fn, cost_guide=cguide,
+                          cost_threshold=float(fx['cost_threshold']), **fixture_kwargs(fx))
+    raw_obs = norm.unnormalize(fx['cond0'], 'observations')
+    policy({0: raw_obs}, batch_size=B, verbose=False)                 # first call: builds the captured loop
+    moved = [0]
+
+    def counted(name):
+        orig = getattr(torch.Tensor, name)
+
+        def wrapper(self, *a, **k):
+            to_host = self.is_cuda and (name != 'to' or any(str(v) == 'cpu' for v in list(a) + list(k.values())))
+            if to_host:
+                moved[0] += self.numel() * self.element_size()
+            return orig(self, *a, **k)
+        monkeypatch.setattr(torch.Tensor, name, wrapper)
+    for name in ('cpu', 'item', 'tolist', 'numpy', 'to', '__array__'):
+        counted(name)
+    action, traj = policy({0: raw_obs}, batch_size=B, verbose=False)
+    torch.cuda.synchronize()
+    assert action.shape == (act,) and np.isfinite(action).all()
+    assert 0 < moved[0] < 1024, moved[0]
+    # the plans are still there for a caller that wants them (and reading them is what moves the bytes)
+    assert traj.actions.shape == (B, int(fx['H']), act)
+    assert moved[0] >= B * int(fx['H']) * (act + obs) * 4
+    assert rel_err(action, traj.actions[0, 0]) < 1e-6
+
+
+def test_host_normalizer_and_custom_sample_fn_routes(setup):
+    """A normalizer without Gaussian statistics keeps its own arithmetic (on the observation and the selected action
+    only), and a custom sample_fn falls back to the reference's step-by-step flow: both give the device path's plan."""
+    from diffuser.sampling import GuidedPolicy, n_step_guided_and_constrained_p_sample as fn
+    fx, diff, guide, cguide, norm = setup
+    B = int(fx['B'])
+
+    class Opaque:                                                    # same arithmetic, no statistics to take to the device
+        def normalize(self, x, key):
+            return norm.normalize(x, key)
+
+        def unnormalize(self, x, key):
+            return norm.unnormalize(x, key)
+    noise = torch.from_numpy(fx['noise']).cuda()
+    kw = dict(cost_guide=cguide, cost_threshold=float(fx['cost_threshold']), noise=noise, **fixture_kwargs(fx))
+    raw_obs = norm.unnormalize(fx['cond0'], 'observations')
+    a0, t0 = GuidedPolicy(guide, diff, norm, [], sample_fn=fn, **kw)({0: raw_obs}, batch_size=B, verbose=False)
+    a1, t1 = GuidedPolicy(guide, diff, Opaque(), [], sample_fn=fn, **kw)({0: raw_obs}, batch_size=B, verbose=False)
+    a2, t2 = GuidedPolicy(guide, diff, norm, [], sample_fn=lambda *a, **k: fn(*a, **k), **kw)({0: raw_obs}, batch_size=B,
+                                                                                              verbose=False)
+    assert rel_err(a1, a0) < 1e-5 and rel_err(a2, a0) < TOL
+    assert rel_err(t1.actions, t0.actions) < 1e-5 and rel_err(t2.observations, t0.observations) < TOL

@@ -239,3 +239,94 @@ def test_new_weights_after_a_captured_loop_are_used():
     assert torch.equal(second.trajectories, fresh.trajectories) and torch.equal(second.values, fresh.values)
     assert not torch.equal(first.trajectories, second.trajectories)
     assert len(diff._samplers) == 1                  # the loop captured on the old weights is gone
+
+
+def test_reference_checkpoint_route_reaches_the_kernels(tmp_path):
+    """weights written in the reference Trainer's file format ({'step','model','ema'} of
+    state_dicts, diffuser/utils/training.py:141-155; the value / cost models with loss_type 'value_l2', i.e. WITHOUT a
+    loss_fn.weights entry, config/locomotion.py:94,137) -> checkpoint.load_into (weights_only) -> re-pack -> the fused
+    loop reproduces the reference's golden chain.  No pretrained TREBI file exists offline, so the file's CONTENT is
+    the golden fixture's seeded weights: the route is pinned, end-task scores are not ('parity unpinned' for those)."""
+    import os
+    from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
+    from diffuser.sampling import ValueGuide
+    from trebi_amd import checkpoint
+    fx = load_fixture('halfcheetah')
+    sd_u, sd_r, sd_c, um, vm = fixture_weights(fx)
+    H, obs, act, dim, T = int(fx['H']), int(fx['obs']), int(fx['act']), int(fx['dim']), int(fx['T'])
+    D, B = obs + act, int(fx['B'])
+    dk = dict(n_timesteps=T, clip_denoised=False, predict_epsilon=False)
+
+    def fresh():
+        return (GaussianDiffusion(TemporalUnet(H, D, 0, dim=dim, dim_mults=um), H, obs, act, loss_type='l2', **dk),
+                ValueDiffusion(ValueFunction(H, D, 0, dim=dim, dim_mults=vm), H, obs, act, loss_type='value_l2', **dk),
+                ValueDiffusion(ValueFunction(H, D, 0, dim=dim, dim_mults=vm), H, obs, act, loss_type='value_l2', **dk))
+    # "training run": modules holding the fixture weights, saved the way Trainer.save does
+    src = fresh()
+    for m, sd in zip(src, (sd_u, sd_r, sd_c)):
+        m.model.load_state_dict({n: torch.from_numpy(v) for n, v in sd.items()}, strict=True)
+    paths = []
+    for i, m in enumerate(src):
+        p = os.path.join(tmp_path, f'run{i}', 'state_200000.pt')
+        os.makedirs(os.path.dirname(p))
+        noise_sd = {k: torch.randn_like(v) if v.dtype.is_floating_point and k.startswith('model.') else v.clone()
+                    for k, v in m.state_dict().items()}                      # 'model' != 'ema': planning must take 'ema'
+        torch.save({'step': 200000, 'model': noise_sd, 'ema': m.state_dict()}, p)
+        paths.append(p)
+    assert not any(k.startswith('loss_fn') for k in src[1].state_dict())
+    # "planning run": default-initialised modules + the files
+    dst = fresh()
+    for m, p in zip(dst, paths):
+        assert checkpoint.load_into(m, p) == 200000
+    diff, guide, cguide = dst[0].cuda(), ValueGuide(dst[1]).cuda(), ValueGuide(dst[2]).cuda()
+    fn, kw = _args(fx, 'constrained', guide, cguide)
+    cond = {0: torch.from_numpy(fx['cond0']).cuda()[None].repeat(B, 1)}
+    s = diff.p_sample_loop((B, H, D), cond, verbose=False, return_chain=True, sample_fn=fn,
+                           noise=torch.from_numpy(fx['noise']).cuda(), **kw)
+    _check(fx, 'constrained', s)
+
+
+def test_sampler_run_only_enqueues_and_is_capturable():
+    """include/trebi_hip.h: after trebi_sampler_bind, trebi_sampler_run neither allocates nor synchronises -- so a
+    use_graph=0 sampler can be captured into the CALLER's graph (here torch's) and replayed; and run refuses buffers
+    it was not bound to."""
+    import ctypes as C
+    from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
+    from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
+    from trebi_amd import _lib
+    fx = load_fixture('pendulum')
+    sd_u, sd_r, sd_c, um, vm = fixture_weights(fx)
+    H, obs, act, dim, T = int(fx['H']), int(fx['obs']), int(fx['act']), int(fx['dim']), int(fx['T'])
+    D, B = obs + act, int(fx['B'])
+    dk = dict(n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False)
+    diff = GaussianDiffusion(_mk(TemporalUnet, sd_u, H, D, 0, dim=dim, dim_mults=um), H, obs, act, **dk).cuda()
+    guide = ValueGuide(ValueDiffusion(_mk(ValueFunction, sd_r, H, D, 0, dim=dim, dim_mults=vm), H, obs, act, **dk)).cuda()
+    cguide = ValueGuide(ValueDiffusion(_mk(ValueFunction, sd_c, H, D, 0, dim=dim, dim_mults=vm), H, obs, act, **dk)).cuda()
+    cond = {0: torch.from_numpy(fx['cond0']).cuda()[None].repeat(B, 1)}
+    noise = torch.from_numpy(fx['noise']).cuda()
+    thr = torch.full((B,), float(fx['cost_threshold']), device='cuda')
+    kw = dict(guide=guide, cost_guide=cguide, cost_threshold=thr, **fixture_kwargs(fx))
+    x, v, c, _ = diff.sample_raw((B, H, D), cond, sample_fn=fn, noise=noise, use_graph=False, **kw)   # creates + binds
+    torch.cuda.synchronize()
+    want = (x.clone(), v.clone(), c.clone())
+    s = next(iter(diff._samplers.values()))
+    lib = _lib.lib()
+
+    def run():
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return lib.trebi_sampler_run(s['h'], _lib.ptr(s['noise']), _lib.ptr_array(s['cond']), _lib.ptr(s['thr']),
+                                     _lib.ptr(s['x']), _lib.ptr(s['values']), _lib.ptr(s['costs']), None, st)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rc = run()
+    assert rc == 0, lib.trebi_last_error()
+    for t in (s['x'], s['values'], s['costs']):
+        t.fill_(float('nan'))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(s['x'], want[0]) and torch.equal(s['values'], want[1]) and torch.equal(s['costs'], want[2])
+    # unbound pointers are refused, not silently re-planned
+    other = torch.empty_like(s['x'])
+    rc = lib.trebi_sampler_run(s['h'], _lib.ptr(s['noise']), _lib.ptr_array(s['cond']), _lib.ptr(s['thr']), _lib.ptr(other),
+                               _lib.ptr(s['values']), _lib.ptr(s['costs']), None, None)
+    assert rc == -1 and b'trebi_sampler_bind' in lib.trebi_last_error()
