@@ -126,7 +126,7 @@ def unet_utilisation(unet, device, batch=8192, iters=10):
     latency-bound -- the UNet forward alone at config 4's per-GPU size (8192 candidates), algorithmic FLOPs (zero-padding
     taps excluded) over HIP-event time on the launch stream, against the fp32 matrix peak."""
     x = torch.randn(batch, H, OBS + ACT, device=device)
-    t = torch.full((batch,), 5, device=device, dtype=torch.long)
+    t = 5                                  # a Python int: range-checked on the host, no device read-back per call
     for _ in range(2):
         unet(x, None, t)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -332,10 +332,14 @@ def main():
     # rehearsal on a one-GPU box: TREBI_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
     # ranks on one device); the driver's runs use one GPU per rank over RCCL
     rehearse = os.environ.get('TREBI_BENCH_REHEARSE') == '1'
+    def phase(name):                          # rehearsal only: progress on stderr + a watchdog re-armed per phase
+        if rehearse:
+            import faulthandler
+            faulthandler.dump_traceback_later(150, exit=True)  # a phase that hangs says where
+            print(f'[rank {rank}] {name}', file=sys.stderr, flush=True)
     if rehearse:
         local = 0
-        import faulthandler
-        faulthandler.dump_traceback_later(75, exit=True)      # a rehearsal that hangs says where
+        phase('start')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
@@ -374,6 +378,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    phase('headline loop')
     for _ in range(max(args.warmup, 1)):
         plan = step()
     fence()
@@ -390,6 +395,7 @@ def main():
 
     # ---- roofline of the dominant kernel (the implicit-GEMM conv), measured live with HIP events on
     # the launch stream: one profiled planning call with plain launches bracketed by events.
+    phase('profiled call')
     lo, hi = plan.local_slice
     diff.sample_raw((hi - lo, H, D), {0: obs[None].expand(hi - lo, -1)}, sample_fn=fn, cost_threshold=thr,
                     profile=True, **kw)
@@ -397,11 +403,15 @@ def main():
     prof = diff.last_profile
 
     ctl = control_step_extra(diff, guide, cguide, thr, device, B) if (rank == 0 and world == 1 and not args.no_unet_util) else None
+    phase('variants')
     var = None if args.no_unet_util else variants(diff, planner, obs, n_global, guide, cguide, thr, device, world)
+    phase('training step')
     train = None if args.no_train else train_step_extra(device, world, rank, cpu=not args.no_cpu_baseline)
     # configs[2] / configs[3]: per-GPU sizes on one GPU; sharded at their global sizes under world > 1 (strong scaling)
+    phase('other configs')
     others = None if args.no_unet_util else other_configs(device, world=world, rank=rank, rehearse=rehearse)
 
+    phase('report')
     if rank == 0:
         F_unet = diff.model.flops()
         F_vf = guide._net().flops() + guide._net().flops(backward=True)
@@ -437,6 +447,9 @@ def main():
                          'kernel': 'implicit-GEMM Conv1d on f32 MFMA (conv_gemm_kernel + resident_chain_kernel)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_note': 'bytes per conv_gemm_kernel launch leaving the L2s (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 '
+                                         '--pmc, profiles/): fabric traffic -- weights re-fetched by every XCD after each kernel '
+                                         'boundary, mostly served by the 256 MB Infinity Cache, not HBM',
                          'avg_launch_us': avg_us, 'launches_per_step': prof['gemm_launches'],
                          'algorithmic_flops_per_launch': flops_per_launch,
                          'eager_loop_ms': prof['loop_us'] / 1e3},

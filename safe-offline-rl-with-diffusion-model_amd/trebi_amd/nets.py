@@ -154,17 +154,23 @@ class _HipNet(nn.Module):
 
     def _time(self, time, B, device):
         """[B] int64 timesteps, range-checked on the host: the kernels index per-timestep tables built for
-        t in [0, max_timesteps) (the reference evaluates its embedding for any t; here that is refused loudly)."""
-        t = torch.as_tensor(time, device=device)
+        t in [0, max_timesteps) (the reference evaluates its embedding for any t; here that is refused loudly).
+        A Python int or a CPU tensor is checked before it is uploaded (no device read-back); a CUDA tensor costs one."""
+        if not (torch.is_tensor(time) and time.is_cuda):
+            t = torch.as_tensor(time)
+            if t.numel():
+                lo, hi = int(t.min()), int(t.max())
+            t = t.to(device=device, dtype=torch.int64)
+        else:
+            t = time.to(torch.int64)
+            if t.numel():
+                lo, hi = (int(v) for v in torch.aminmax(t))          # one read-back; the fused loop never comes here
         if t.dim() == 0:
             t = t.expand(B)
-        t = t.to(torch.int64).contiguous()
-        if t.numel():
-            lo, hi = (int(v) for v in torch.aminmax(t))              # one read-back; the fused loop never comes here
-            if lo < 0 or hi >= self.max_timesteps:
-                raise RuntimeError(f'timesteps must lie in [0, {self.max_timesteps}) (set_max_timesteps sizes the '
-                                   f'tables); got [{lo}, {hi}]')
-        return t
+        if t.numel() and (lo < 0 or hi >= self.max_timesteps):
+            raise RuntimeError(f'timesteps must lie in [0, {self.max_timesteps}) (set_max_timesteps sizes the '
+                               f'tables); got [{lo}, {hi}]')
+        return t.contiguous()
 
 
 class TemporalUnet(_HipNet):

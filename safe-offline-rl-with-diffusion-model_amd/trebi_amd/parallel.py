@@ -32,12 +32,15 @@ class ShardedPlanner:
         self.diffusion = diffusion
         self.group = group
         self._bufs = {}
-        # how the exchange is ordered behind the captured loop: 'host' = drain the launch stream (default for gloo and
-        # whenever TREBI_PLAN_SYNC=1), 'stream' = leave it to the backend's own event wait (default for RCCL)
+        # How the exchange is ordered behind the captured loop.  'host' (default, every backend): drain the launch
+        # stream first -- free, the scores are read on the host right after the exchange.  'stream' (TREBI_PLAN_SYNC=0):
+        # leave the ordering to the backend's own event wait.  Measured on a one-GPU box with two gloo ranks
+        # (tools/rehearse_two_samplers.py, profiles/r02_stall_diagnostic.txt): with 'stream' the FIRST exchange queued
+        # behind a pending hipGraphLaunch never completes (gloo records an event behind the graph, lets a pool stream
+        # wait for it and copies to the host from there); with 'host' 24 of 24 exchanges pass.  RCCL could not be run
+        # on that box (one GPU), so the safe fence is the default for it too.
         if fence is None:
-            env = os.environ.get('TREBI_PLAN_SYNC')
-            backend = dist.get_backend(group) if dist.is_available() and dist.is_initialized() else 'none'
-            fence = 'host' if (env == '1' or (env is None and backend != 'nccl')) else 'stream'
+            fence = 'stream' if os.environ.get('TREBI_PLAN_SYNC') == '0' else 'host'
         self.fence = fence
         if local_fn is None:
             def local_fn(shape, cond, noise=None, **kw):

@@ -14,7 +14,7 @@ H, D = 32, 23
 net = TemporalUnet(H, D, 0, dim=32, dim_mults=mults)
 net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec.unet_param_shapes(H, D, 32, mults), 1).items()})
 net.set_max_timesteps(20); net = net.cuda()
-x = torch.randn(B, H, D, device='cuda'); t = torch.full((B,), 5, device='cuda', dtype=torch.long)
+x = torch.randn(B, H, D, device='cuda'); t = 5
 for _ in range(3):
     net(x, None, t)
 torch.cuda.synchronize()
