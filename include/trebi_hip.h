@@ -79,6 +79,19 @@ int trebi_net_create(trebi_ctx* ctx, const trebi_net_desc* desc, const char* con
                      trebi_net** out);
 void trebi_net_destroy(trebi_net* net);
 
+/* Operand precision of the convolutions (opt-in; default 0).  No counterpart in the reference (fp32 throughout).
+ *   0  f32     v_mfma_f32_16x16x4_f32, exact fp32 products
+ *   1  bf16x3  every fp32 operand split into two bf16 halves (x = hi + lo), a product computed as
+ *              hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: ~2^-16 relative error per
+ *              product, 5.3x the fp32 matrix rate.  Engaged for launches of at least min_batch candidates
+ *              (<= 0: keep the current threshold, initially 512) and for the layers that can take it (whole
+ *              32-channel steps, no fused GroupNorm-backward prologue); everything else stays on the fp32 pipe.
+ *              GroupNorm statistics, Mish and all accumulation stay fp32.  Stated bound: network outputs and guide
+ *              gradients within 1e-3 of the reference (tests/test_gpu_bf16.py).
+ * A set-up call (allocates the bf16x3 weight copies on first use, synchronises); samplers created on the net
+ * before the call keep their launch plans: create them afterwards. */
+int trebi_net_set_precision(trebi_net* net, int mode, int min_batch);
+
 /* Number of reference state_dict entries the descriptor implies, and the i-th name/numel
  * (lets the caller check a checkpoint before handing it over; serialization.py:36-60). */
 int trebi_net_param_count(const trebi_net_desc* desc);
@@ -270,6 +283,9 @@ double trebi_trainer_flops(const trebi_trainer* tr, int backward);
 int trebi_trainer_bind(trebi_trainer* tr, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                        float* ema, const float* loss_weights, const float* sqrt_alphas_cumprod,
                        const float* sqrt_one_minus_alphas_cumprod);
+/* trebi_net_set_precision for the trainer's convolutions (forward and input-gradient; the weight-gradient GEMM
+ * stays fp32). */
+int trebi_trainer_set_precision(trebi_trainer* tr, int mode, int min_batch);
 /* After the caller changed `params` itself (load_state_dict): re-pack the kernels' copies. */
 int trebi_trainer_repack(trebi_trainer* tr, void* stream);
 

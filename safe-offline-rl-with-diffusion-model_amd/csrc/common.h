@@ -108,6 +108,8 @@ struct Tile {
   // Identity residual read straight from global memory in the epilogue instead of being staged as an LDS tile:
   // costs a memory round trip there, frees 16*MI x (TN+4) floats -- what lets 16 candidates fit the backward layers.
   int resg = 0;
+  // bf16x3 operands (conv.hip, device_util.h): the launch's weight pointers are the bf16x3 copies
+  int bf = 0;
 };
 
 size_t conv_lds_bytes(const ConvP& p, const Tile& tl);
@@ -164,6 +166,7 @@ hipError_t launch_policy_prepare(const float* obs, int n_obs, int obs_dim, const
                                  float* cond, const float* thr, int n_thr, float* thr_out, hipStream_t st);
 hipError_t launch_policy_action(const float* x, int H, int D, int act, const long long* index, int n, int B,
                                 const float* mean, const float* stdv, float* out, hipStream_t st);
+hipError_t launch_pack_bf16x3(const float* w32, float* w16, int steps16, int Npad, hipStream_t st);
 hipError_t launch_fill_t(long long* t, int B, int value, hipStream_t st);
 hipError_t launch_fill_f(float* p, int n, float value, hipStream_t st);
 hipError_t launch_feasibility(const float* ry, const float* cy, const float* thr, int n, float* out,

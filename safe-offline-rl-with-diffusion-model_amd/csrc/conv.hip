@@ -64,6 +64,7 @@ ConvGeo conv_make_geo(const ConvP& p, const Tile& tl) {
   g.KK1 = p.ntaps * g.cbpt;
   g.KK = g.KK1 + (p.x2 ? (p.Cin2_p >> 4) : 0);
   g.chunk = (g.KK + g.KS - 1) / g.KS;
+  if (tl.bf) g.chunk = (g.KK / 2 + g.KS - 1) / g.KS * 2;      // bf16x3 consumes 16-channel units in (hi, lo) pairs
   int nA = g.S * g.R * g.ldA, n2 = p.x2 ? g.S * p.Lout * g.ld2 : 0, nY = p.pro ? g.S * p.Lin * g.ldA : 0;
   g.oSlab2 = nA;
   g.oY = nA + n2;
@@ -128,7 +129,12 @@ struct ConvPre {
   int chunk, KK, KK1;
 };
 
-template <int MI, int NI, bool VEC, bool PM>
+// BF: operands as bf16 hi/lo pairs (bf16x3, see device_util.h): the packed weights `pre.w` are then the bf16x3 copy
+// (same addressing: a 16-byte unit per (step, lane group, column); unit 2k is the hi half, 2k+1 the lo half of the
+// 32-channel step k), the staged activations are converted once on their way into LDS (a row keeps its byte size: hi
+// plane then lo plane), and the K loop issues three 16x16x32 bf16 MFMAs per 32 channels.  Layers with the fused
+// GroupNorm-backward prologue are not taken in this mode (the host keeps them on the fp32 pipe).
+template <int MI, int NI, bool VEC, bool PM, bool BF>
 __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float* smem, const int by, const int n0,
                                           const int tid) {
   constexpr int WB = (NI == 1) ? (MI <= 2 ? 24 : 16) : 8;
@@ -164,7 +170,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
   // entered by one branch per block of BS steps, so every A operand of a block is requested from LDS before its
   // first MFMA (a branch per step exposed the LDS latency at every step), and two accumulators per source, one for
   // even and one for odd slots (a single chain pays the 40-cycle dependent-MFMA latency instead of the 32-cycle issue).
-  constexpr bool STR = MI == 1 && NI == 1 && !PM;
+  constexpr bool STR = MI == 1 && NI == 1 && !PM && !BF;
   constexpr int BS = 8;
   const int n1 = (k_end < KK1 ? k_end : KK1) > k_begin ? (k_end < KK1 ? k_end : KK1) - k_begin : 0;   // first-source steps
   const int n2 = k_end - k_begin - n1;                                                              // second-source steps
@@ -279,11 +285,12 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
     {
       const FastDiv dC4(CG(c4n), CG(mC4)), dNv(nv, CG(mNv));
       const int c4n = CG(c4n), total = CG(nValid4), vlo = CG(vlo);
+      const int Cin_p_ = cbpt * 16;
       const float* pg = CP(pro_g);
       const float* py = CP(pro_y);
       for (int base = tid; base < total; base += 4 * nthr) {
         f32x4 v[4], m[4], y[4];
-        int so[4], yo[4];
+        int so[4], yo[4], sc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           int idx = base + u * nthr;
@@ -292,6 +299,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
             int rowv = dC4.div(idx), c4 = idx - rowv * c4n;
             int s = dNv.div(rowv), i = rowv - s * nv;
             so[u] = (s * R + fh + i) * ldA + 4 * c4;
+            sc[u] = 4 * c4;
             yo[u] = (s * Lin + i) * ldA + 4 * c4;
             unsigned grow = (unsigned)(b0 + s) * Lin + vlo + i;
             int left = s < nvs ? Cin - 4 * c4 : 0;
@@ -308,6 +316,8 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
             if (haspro) {
               *(f32x4*)&slab[so[u]] = v[u] * m[u];
               *(f32x4*)&yslab[yo[u]] = y[u];
+            } else if constexpr (BF) {
+              store4_bf16x2(slab + so[u] - sc[u], sc[u], Cin_p_, v[u]);
             } else {
               *(f32x4*)&slab[so[u]] = v[u];
             }
@@ -329,20 +339,24 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
       const unsigned ldx2 = CP(ldx2);
       for (int base = tid; base < total; base += 2 * nthr) {
         f32x4 v[2];
-        int so[2] = {-1, -1};
+        int so[2] = {-1, -1}, sc[2] = {0, 0};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           int idx = base + u * nthr;
           if (idx < total) {
             int row = dC4.div(idx), c4 = idx - row * c4n;
             so[u] = row * ld2 + 4 * c4;
+            sc[u] = 4 * c4;
             int left = row < nvs * Lout ? C2 - 4 * c4 : 0;
             v[u] = load4<VEC>(p2 + ((unsigned)b0 * Lout + row) * ldx2 + 4 * c4, left);
           }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-          if (so[u] >= 0) *(f32x4*)&slab2[so[u]] = v[u];
+          if (so[u] >= 0) {
+            if constexpr (BF) store4_bf16x2(slab2 + so[u] - sc[u], sc[u], 4 * c4n, v[u]);
+            else *(f32x4*)&slab2[so[u]] = v[u];
+          }
       }
     }
     if (haspro) {
@@ -494,7 +508,70 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
       }
     }
   };
-  if (multi) {
+  // bf16x3: register slots u / u+1 hold the hi / lo weight halves of the 32-channel step (kk, kk+1); in float units a
+  // row's hi plane advances 16 per step and the lo plane sits Cin_p/2 behind it (byte for byte the fp32 row).
+  const int lo1 = cbpt * 8, lo2 = CP(Cin2_p) >> 1;
+  auto mma3 = [&](f32x4(&ac)[MI][NI], const f32x4(&ah)[MI], const f32x4(&al)[MI], const bool(&on)[MI], int u) {
+#pragma unroll
+    for (int term = 0; term < 3; ++term)       // hi*hi, hi*lo, lo*hi; tile-major inside a term: no back-to-back dependency
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        if (on[mi]) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            ac[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(term == 2 ? al[mi] : ah[mi]),
+                                                                 as_bf16x8(wreg[term == 1 ? u + 1 : u][ni]), ac[mi][ni],
+                                                                 0, 0, 0);
+        }
+  };
+  auto kstep2 = [&](int u, int kk, int& tau, int& cb, int& aoff) {
+    if (kk < k_end) {
+      f32x4 ah[MI], al[MI];
+      bool on[MI];
+      if (kk < KK1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          on[mi] = !PM || (unsigned)(jlo[mi] + tau) < (unsigned)nv;       // zero padding is skipped as a whole
+          if (on[mi]) {
+            ah[mi] = *(const f32x4*)&slab[rowA[mi] + aoff];
+            al[mi] = *(const f32x4*)&slab[rowA[mi] + aoff + lo1];
+          }
+        }
+        mma3(acc, ah, al, on, u);
+        aoff += 16;
+        cb += 2;
+        if (cb == cbpt) { cb = 0; ++tau; aoff += ldA - cbpt * 8; }
+      } else {
+        const int a2 = ((kk - KK1) >> 1) * 16;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          on[mi] = true;
+          ah[mi] = *(const f32x4*)&slab2[row2[mi] + a2];
+          al[mi] = *(const f32x4*)&slab2[row2[mi] + a2 + lo2];
+        }
+        mma3(acc2, ah, al, on, u);
+      }
+    }
+  };
+  if constexpr (BF) {
+    if (multi) {
+      for (int base = k_begin; base < k_end; base += WB) {
+        int tau = dCb.div(base), cb = base - tau * cbpt;
+        int aoff = tau * ldA + cb * 8;
+#pragma unroll
+        for (int u = 0; u < HB; u += 2) kstep2(u, base + u, tau, cb, aoff);
+        wload(0, base + WB);
+#pragma unroll
+        for (int u = HB; u < WB; u += 2) kstep2(u, base + u, tau, cb, aoff);
+        wload(HB, base + WB + HB);
+      }
+    } else {
+      int tau = dCb.div(k_begin), cb = k_begin - tau * cbpt;
+      int aoff = tau * ldA + cb * 8;
+#pragma unroll
+      for (int u = 0; u < WB; u += 2) kstep2(u, k_begin + u, tau, cb, aoff);
+    }
+  } else if (multi) {
     for (int base = k_begin; base < k_end; base += WB) {
       int tau = dCb.div(base), cb = base - tau * cbpt;
       int aoff = tau * ldA + cb * 16;
@@ -702,7 +779,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
 }
 
 constexpr int CPRE_DW = 12;          // dwords of kernel arguments in front of the descriptor (11 used + alignment)
-template <int MI, int NI, bool VEC, bool PM>
+template <int MI, int NI, bool VEC, bool PM, bool BF>
 __global__ __launch_bounds__(512) void conv_gemm_kernel(const float* w0, const float* w1, int Npad, int TN, int NG,
                                                         unsigned mNG, int chunk, int KK, int KK1, ConvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -720,7 +797,7 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const float* w0, const f
   // blockIdx.x = column tile, blockIdx.y = candidate group: workgroups are dealt to the 8 XCDs round-robin by
   // linear id, so the workgroups that share a weight slice land on the same XCD (one L2 fetches the slice
   // instead of all eight; the activations are tiny)
-  conv_body<MI, NI, VEC, PM>(dv, pre, smem, blockIdx.y, blockIdx.x * TN, threadIdx.x);
+  conv_body<MI, NI, VEC, PM, BF>(dv, pre, smem, blockIdx.y, blockIdx.x * TN, threadIdx.x);
 }
 
 template <int MI, int NI, bool PM>
@@ -736,11 +813,16 @@ static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hip
   const float* w0 = L.p[0].w;
   const float* w1 = L.p[nz > 1 ? 1 : 0].w;
   static_assert(offsetof(ConvLaunch, p) == 0 && alignof(ConvLaunch) == 8, "descriptor offset in the kernel arguments");
-  if (vec)
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
+  if (tl.bf) {
+    // bf16x3: vector-addressable sources, whole 32-channel steps per tap and per wave, no fused backward prologue
+    if (!vec || p.pro || (p.Cin_p & 31) || (p.x2 && (p.Cin2_p & 31)) || (g.chunk & 1) || (g.KK & 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM, true>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
+                       g.chunk, g.KK, g.KK1, LL);
+  } else if (vec)
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM, false>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
                        g.chunk, g.KK, g.KK1, LL);
   else
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, false, PM>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, false, PM, false>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
                        g.chunk, g.KK, g.KK1, LL);
   return hipGetLastError();
 }
@@ -754,10 +836,13 @@ hipError_t conv_init_device() {
   hipError_t e = hipSuccess;
 #define TREBI_ATTR(mi, ni, pm)                                                                 \
   if (e == hipSuccess)                                                                       \
-    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, true, pm>,                 \
+    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, true, pm, false>,          \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
   if (e == hipSuccess)                                                                       \
-    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, false, pm>,                \
+    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, true, pm, true>,           \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+  if (e == hipSuccess)                                                                       \
+    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, false, pm, false>,         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   TREBI_TILES(TREBI_ATTR)
 #undef TREBI_ATTR

@@ -63,6 +63,34 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- bf16x3: fp32 operands split into two bf16 halves, x = hi + lo (+ O(2^-17 |x|)) ---------------------------
+// A product is then hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): 3 instructions of 16 cycles
+// for K = 32 instead of 8 of 32 cycles on the fp32 matrix pipe, at a relative error of ~2^-16 per product.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned bf16_rne(float x) {          // float -> bf16 bits, round to nearest even
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split_bf16(float x, unsigned* hi, unsigned* lo) {
+  const unsigned h = bf16_rne(x);
+  *hi = h;
+  *lo = bf16_rne(x - __uint_as_float(h << 16));
+}
+// four consecutive channels of one row -> the row's hi plane (bf16 [Cp]) and lo plane (bf16 [Cp] behind it)
+__device__ __forceinline__ void store4_bf16x2(float* row, int c, int Cp, f32x4 v) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split_bf16(v[q], &h[q], &l[q]);
+  unsigned short* b = (unsigned short*)row;
+  *(uint2*)(b + c) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+  *(uint2*)(b + Cp + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(f32x4 v) {
+  union { f32x4 f; bf16x8 b; } c;
+  c.f = v;
+  return c.b;
+}
+
 // n / d with a host-computed multiplier (ConvGeo): one mul-hi.
 struct FastDiv {
   unsigned d, m;

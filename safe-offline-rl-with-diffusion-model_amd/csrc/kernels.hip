@@ -274,6 +274,43 @@ hipError_t launch_policy_action(const float* x, int H, int D, int act, const lon
   return hipGetLastError();
 }
 
+// ----------------------------------------------------------------------------------
+// bf16x3 copy of a packed weight block: [(K/16)][4][Npad][4] fp32 -> per 32-channel step k two 16-byte-per-(lane group,
+// column) planes, unit 2k = the eight hi halves, unit 2k+1 the eight lo halves, of channels 32k + 8g .. +7 (the B operand of
+// v_mfma_f32_16x16x32_bf16: lane l holds k = 8(l>>4)+j of column l&15); same addressing as the fp32 layout.
+// ----------------------------------------------------------------------------------
+__global__ void pack_bf16x3_kernel(const float* w32, unsigned short* w16, int steps16, int Npad) {
+  const long total = (long)(steps16 / 2) * 4 * Npad;          // one thread per (32-step, lane group, column)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % Npad);
+    const long r = i / Npad;
+    const int g = (int)(r & 3);
+    const long k32 = r >> 2;
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int within = 8 * g + e;                               // channel inside the 32-step
+      const long k16 = 2 * k32 + (within >> 4);
+      const int g16 = (within & 15) >> 2, j = within & 3;
+      unsigned h, l;
+      split_bf16(w32[((k16 * 4 + g16) * Npad + n) * 4 + j], &h, &l);
+      hi[e] = (unsigned short)h;
+      lo[e] = (unsigned short)l;
+    }
+    unsigned short* ph = w16 + (((2 * k32) * 4 + g) * Npad + n) * 8;
+    unsigned short* pl = w16 + (((2 * k32 + 1) * 4 + g) * Npad + n) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ph[e] = hi[e]; pl[e] = lo[e]; }
+  }
+}
+hipError_t launch_pack_bf16x3(const float* w32, float* w16, int steps16, int Npad, hipStream_t st) {
+  const long total = (long)(steps16 / 2) * 4 * Npad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(blocks), dim3(256), 0, st, w32, (unsigned short*)w16, steps16, Npad);
+  return hipGetLastError();
+}
+
 __global__ void fill_t_kernel(long long* t, int B, int value) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) t[i] = value;
 }

@@ -387,6 +387,8 @@ static int trainer_repack(trebi_trainer* tr, hipStream_t st) {
     else
       HIPCHK(launch_time_linear(j.w, j.ldw, j.col0, j.b, net->tt_temb, dim, T, j.N, j.mish, j.out, st));
   }
+  if (net->prec == 1)
+    if (int e = net_refresh_bf16(net, st)) return e;
   return 0;
 }
 
@@ -459,10 +461,23 @@ extern "C" int trebi_trainer_bind(trebi_trainer* tr, float* params, float* grads
   return 0;
 }
 
+extern "C" int trebi_trainer_set_precision(trebi_trainer* tr, int mode, int min_batch) {
+  if (!tr) return fail(TREBI_BAD_ARG, "null trainer");
+  if (int e = trebi_net_set_precision(tr->net, mode, min_batch)) return e;
+  if (tr->bound && mode == 1)
+    if (int e = net_refresh_bf16(tr->net, 0)) return e;
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+
 namespace {
-int launch_op(const Op& op, const Resolver& r, const Tile& tl, hipStream_t st) {
+int launch_op(const Op& op, const Resolver& r, Tile tl, hipStream_t st) {
   ConvLaunch L{};
   L.p[0] = r.conv(op);
+  if (use_bf(r.net, op, r.B) && conv_vec_ok(L.p[0])) {
+    tl.bf = 1;
+    L.p[0].w = op.w16;
+  }
   if (tl.S * op.Lout > 16 * tl.MI || op.Npad % (16 * tl.NI * tl.NG) || 64 * tl.NG * tl.KS > 512 || !L.p[0].x || !L.p[0].out)
     return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
   HIPCHK(launch_conv(L, 1, tl, st));

@@ -97,6 +97,7 @@ struct Op {
   int Lin = 0, Lout = 0, stride = 1, pad = 0, tap_lo = 0, ntaps = 1;
   int Cin = 0, Cin_p = 0, Cin2 = 0, Cin2_p = 0, N = 0, Npad = 0, osplit = 0;
   const float* w = nullptr;
+  const float* w16 = nullptr;       // bf16x3 copy of the packed weights (trebi_net_set_precision), or null
   const float* bias = nullptr;
   const float* bias2 = nullptr;
   bool gn = false;
@@ -182,6 +183,11 @@ struct trebi_net {
   float head_b2 = 0.f;
   int fc = 0, hd = 0;
   double flops_fwd = 0, flops_bwd = 0;
+  // bf16x3 operand mode (trebi_net_set_precision): copies of the packed weights, engaged from bf_min_b candidates up
+  int prec = 0, bf_min_b = 512;
+  struct BfJob { const float* w32; float* w16; int steps16, Npad; };
+  std::vector<BfJob> bf_jobs;
+  void* bf_arena = nullptr;
   // training (trainer.inl): every uploaded region (so that it can be re-packed from the flat parameters), the
   // time-table jobs to re-run after a re-pack, the forward graph record and the backward step list
   bool train = false;
@@ -198,6 +204,7 @@ struct trebi_net {
 
   ~trebi_net() {
     for (void* p : allocs) (void)hipFree(p);
+    if (bf_arena) (void)hipFree(bf_arena);
   }
   int new_buf(size_t per_sample) {
     buf_per_sample.push_back(per_sample);
@@ -1050,6 +1057,11 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
   return best;
 }
 
+// A layer runs with bf16x3 operands when its net is in that mode, has the copy, and the batch is large enough.
+inline bool use_bf(const trebi_net* n, const Op& op, int B) {
+  return n && n->prec == 1 && op.w16 != nullptr && B >= n->bf_min_b;
+}
+
 struct Resolver {
   const trebi_net* net;
   std::vector<size_t> off;
@@ -1145,6 +1157,11 @@ int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, 
     if (tl.S * op.Lout > 16 * tl.MI || op.Npad % (16 * tl.NI * tl.NG) || 64 * tl.NG * tl.KS > 512 ||
         (op.pro && (op.stride != 1 || op.Lin != op.Lout)) || !L.p[0].x || !L.p[0].out)
       return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
+    if (use_bf(n0, op, B) && conv_vec_ok(L.p[0]) && (!n1 || (use_bf(n1, (*ops1)[i], B) && conv_vec_ok(L.p[1])))) {
+      tl.bf = 1;
+      L.p[0].w = op.w16;
+      if (n1) L.p[1].w = (*ops1)[i].w16;
+    }
     if (prof && prof->enabled) {
       if (prof->used == prof->ev.size()) {
         hipEvent_t a, b;
@@ -1507,9 +1524,14 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
         (op.pro && (op.stride != 1 || op.Lin != op.Lout)) || !st.L.p[0].x || !st.L.p[0].out)
       return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
     st.flops = op.flops * B * nz;
+    if (use_bf(r0.net, op, B) && conv_vec_ok(st.L.p[0]) && (!r1 || (use_bf(r1->net, *o1[i], B) && conv_vec_ok(st.L.p[1])))) {
+      st.tl.bf = 1;
+      st.L.p[0].w = op.w16;
+      if (r1) st.L.p[1].w = o1[i]->w16;
+    }
     {
       char tb[96];
-      snprintf(tb, sizeof tb, " MI%d NI%d NG%d KS%d S%d%s%s grid %dx%d", st.tl.MI, st.tl.NI, st.tl.NG, st.tl.KS, st.tl.S, st.tl.pm ? " pm" : "", st.tl.resg ? " resg" : "",
+      snprintf(tb, sizeof tb, " MI%d NI%d NG%d KS%d S%d%s%s%s grid %dx%d", st.tl.MI, st.tl.NI, st.tl.NG, st.tl.KS, st.tl.S, st.tl.pm ? " pm" : "", st.tl.resg ? " resg" : "", st.tl.bf ? " bf16x3" : "",
                (B + st.tl.S - 1) / st.tl.S, op.Npad / (16 * st.tl.NI * st.tl.NG));
       st.name = op.name + (op.pro ? " (bwd)" : "") + tb;
     }
@@ -1683,6 +1705,45 @@ extern "C" int trebi_net_create(trebi_ctx* ctx, const trebi_net_desc* desc, cons
   return net_create_impl(ctx, desc, names, tensors, numels, n_tensors, false, out);
 }
 extern "C" void trebi_net_destroy(trebi_net* net) { delete net; }
+
+// (Re)build the bf16x3 copies of every packed weight block from the fp32 ones (after a re-pack while training).
+static int net_refresh_bf16(trebi_net* net, hipStream_t st) {
+  for (auto& j : net->bf_jobs) HIPCHK(launch_pack_bf16x3(j.w32, j.w16, j.steps16, j.Npad, st));
+  return 0;
+}
+
+extern "C" int trebi_net_set_precision(trebi_net* net, int mode, int min_batch) {
+  if (!net) return fail(TREBI_BAD_ARG, "null net");
+  if (mode != 0 && mode != 1) return fail(TREBI_BAD_ARG, "precision mode must be 0 (f32) or 1 (bf16x3)");
+  HIPCHK(hipSetDevice(net->ctx->device));
+  if (mode == 1 && !net->bf_arena) {
+    std::vector<Op*> ops;
+    for (auto& op : net->fwd) ops.push_back(&op);
+    for (auto& op : net->bwd) ops.push_back(&op);
+    for (auto& t : net->tops)
+      if (t.kind == 0) ops.push_back(&t.conv);
+    size_t total = 0;
+    std::vector<size_t> offs;
+    for (Op* op : ops) {
+      const bool ok = op->kind == 0 && !op->pro && op->w && (op->Cin_p % 32) == 0 && (op->Cin2_p % 32) == 0;
+      offs.push_back(ok ? total : (size_t)-1);
+      if (ok) total += ((size_t)((op->ntaps * op->Cin_p + op->Cin2_p) / 16 + 8) * 16 * op->Npad * sizeof(float) + 255) / 256 * 256;
+    }
+    HIPCHK(hipMalloc(&net->bf_arena, std::max<size_t>(total, 256)));
+    for (size_t i = 0; i < ops.size(); ++i) {
+      if (offs[i] == (size_t)-1) continue;
+      Op* op = ops[i];
+      float* w16 = (float*)((char*)net->bf_arena + offs[i]);
+      op->w16 = w16;
+      net->bf_jobs.push_back({op->w, w16, (op->ntaps * op->Cin_p + op->Cin2_p) / 16 + 8, op->Npad});
+    }
+    if (int e = net_refresh_bf16(net, 0)) return e;
+    HIPCHK(hipDeviceSynchronize());
+  }
+  net->prec = mode;
+  if (min_batch > 0) net->bf_min_b = min_batch;
+  return 0;
+}
 
 extern "C" size_t trebi_unet_workspace_bytes(const trebi_net* net, int B) {
   return net && B > 0 ? net->ws_floats(B) * sizeof(float) : 0;

@@ -47,6 +47,8 @@ SIGNATURES = {
     'trebi_net_create': (C.c_int, [_VP, C.POINTER(NetDesc), C.POINTER(C.c_char_p), C.POINTER(_VP),
                                    c_i64_p, C.c_int, C.POINTER(_VP)]),
     'trebi_net_destroy': (None, [_VP]),
+    'trebi_net_set_precision': (C.c_int, [_VP, C.c_int, C.c_int]),
+    'trebi_trainer_set_precision': (C.c_int, [_VP, C.c_int, C.c_int]),
     'trebi_net_param_count': (C.c_int, [C.POINTER(NetDesc)]),
     'trebi_net_param_info': (C.c_int, [C.POINTER(NetDesc), C.c_int, C.c_char_p, C.c_size_t, c_i64_p]),
     'trebi_net_flops': (C.c_double, [_VP, C.c_int]),

@@ -60,6 +60,7 @@ class _HipNet(nn.Module):
         self._handle = None
         self._packed_key = None
         self._ws = {}
+        self.precision = ('f32', 0)               # operand precision of the convolutions (set_precision)
         self.generation = 0                       # bumped whenever the packed weights are rebuilt
         self._dependents = weakref.WeakSet()      # GaussianDiffusion objects holding captured loops on the handle
 
@@ -105,7 +106,29 @@ class _HipNet(nn.Module):
             self._handle, self._packed_key = h, key
             self._ws = {}
             self.generation += 1
+            self._apply_precision(device)
         return self._handle
+
+    def set_precision(self, mode='f32', min_batch=0):
+        """'f32' (default: exact fp32 products on the fp32 matrix pipe) or 'bf16x3' (opt-in: fp32 operands split into
+        two bf16 halves, three bf16 MFMAs per product, fp32 accumulation; ~2^-16 relative error per product, stated
+        bound 1e-3 on network outputs; engaged from `min_batch` candidates up, 512 if 0).  The reference is fp32
+        throughout; this has no counterpart there."""
+        if mode not in ('f32', 'bf16x3'):
+            raise ValueError("precision must be 'f32' or 'bf16x3'")
+        self.precision = (mode, int(min_batch))
+        if self._handle is not None:
+            for d in list(self._dependents):          # launch plans bake the weight pointers in
+                d.drop_samplers_of(self)
+            self._apply_precision(next(self.parameters()).device)
+            self.generation += 1
+        return self
+
+    def _apply_precision(self, device):
+        mode, mb = self.precision
+        if mode == 'bf16x3' or self._handle is not None:
+            with torch.cuda.device(device):
+                _lib.check(_lib.lib().trebi_net_set_precision(self._handle, 1 if mode == 'bf16x3' else 0, mb))
 
     def add_dependent(self, diffusion):
         self._dependents.add(diffusion)

@@ -99,6 +99,14 @@ class TrainEngine:
     def flops(self, backward=False):
         return _lib.lib().trebi_trainer_flops(self.h, 1 if backward else 0)
 
+    def set_precision(self, mode='f32', min_batch=0):
+        """Operand precision of the forward and input-gradient convolutions ('f32' | 'bf16x3', see nets.set_precision);
+        the weight-gradient GEMM, the loss, Adam and the EMA stay fp32."""
+        if mode not in ('f32', 'bf16x3'):
+            raise ValueError("precision must be 'f32' or 'bf16x3'")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().trebi_trainer_set_precision(self.h, 1 if mode == 'bf16x3' else 0, int(min_batch)))
+
     def repack(self):
         """After `params` was changed from outside (load_state_dict on the module)."""
         _lib.check(_lib.lib().trebi_trainer_repack(self.h, self._stream()))

@@ -1,0 +1,111 @@
+"""GPU: the opt-in bf16x3 operand mode (include/trebi_hip.h, trebi_net_set_precision): fp32 operands split into two
+bf16 halves, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulation.
+
+Stated bound: network outputs and guide gradients within 3e-4 relative of the reference's golden vectors (measured
+4e-5 .. 9e-5; the fp32 path: 1e-4 asserted, ~3e-6 measured; north_star's bar for fp32 is 1e-3), 20-step guided chains
+within 5e-4 (measured 6e-5), training gradients within 5e-4 of each tensor's largest element (measured 8e-5).  The mode is forced on at every batch size here
+(min_batch=1); in production it engages from 512 candidates up."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _common import GOLDEN, fixture_kwargs, fixture_weights, load_fixture, rel_err
+from trebi_amd import spec, synth
+
+pytestmark = pytest.mark.gpu
+NET_TOL, CHAIN_TOL, GRAD_TOL = 3e-4, 5e-4, 5e-4
+
+
+def _mk(cls, sd, *a, **k):
+    net = cls(*a, **k)
+    net.load_state_dict({n: torch.from_numpy(v) for n, v in sd.items()}, strict=True)
+    net.set_max_timesteps(20)
+    return net.set_precision('bf16x3', min_batch=1)
+
+
+@pytest.mark.parametrize('name', ['halfcheetah', 'walker148', 'hopper'])
+def test_nets_golden_bf16x3(name):
+    from trebi_amd.nets import TemporalUnet, ValueFunction
+    fx = load_fixture(name)
+    sd_u, sd_r, sd_c, um, vm = fixture_weights(fx)
+    H, D, dim, B = int(fx['H']), int(fx['obs']) + int(fx['act']), int(fx['dim']), int(fx['B'])
+    unet = _mk(TemporalUnet, sd_u, H, D, 0, dim=dim, dim_mults=um).cuda()
+    rnet = _mk(ValueFunction, sd_r, H, D, 0, dim=dim, dim_mults=vm).cuda()
+    x = torch.from_numpy(fx['net_x']).cuda()
+    worst = 0.0
+    for tt in (0, 5, 19):
+        t = torch.full((B,), tt, device='cuda', dtype=torch.long)
+        e = rel_err(unet(x, None, t).cpu().numpy(), fx[f'unet_out_t{tt}'])
+        y, g = rnet.value_and_input_grad(x, t)
+        ey, eg = rel_err(y.cpu().numpy(), fx[f'reward_y_t{tt}']), rel_err(g.cpu().numpy(), fx[f'reward_grad_t{tt}'])
+        worst = max(worst, e, ey, eg)
+        assert e < NET_TOL and ey < NET_TOL and eg < NET_TOL, (tt, e, ey, eg)
+    print(name, 'worst bf16x3 error vs reference:', worst)
+    # the mode really is on: results differ from the fp32 path (which is exact to ~1e-6)
+    f32 = _mk(TemporalUnet, sd_u, H, D, 0, dim=dim, dim_mults=um).set_precision('f32').cuda()
+    t = torch.full((B,), 5, device='cuda', dtype=torch.long)
+    assert not torch.equal(f32(x, None, t), unet(x, None, t))
+
+
+def test_large_batch_chain_bf16x3():
+    """The production route: 600 copies of the golden candidates (>= 512: no resident chains, bf16x3 on the single-layer
+    launches, position-major tiles) must reproduce the golden 20-step constrained plan in every copy."""
+    from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
+    from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
+    fx = load_fixture('halfcheetah')
+    sd_u, sd_r, sd_c, um, vm = fixture_weights(fx)
+    H, obs, act, dim, T = int(fx['H']), int(fx['obs']), int(fx['act']), int(fx['dim']), int(fx['T'])
+    D, Bg, total = obs + act, int(fx['B']), 600
+    kw = dict(n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False)
+    mk = lambda cls, sd, m: _mk(cls, sd, H, D, 0, dim=dim, dim_mults=m).set_precision('bf16x3')     # default threshold (512)
+    diff = GaussianDiffusion(mk(TemporalUnet, sd_u, um), H, obs, act, **kw).cuda()
+    guide = ValueGuide(ValueDiffusion(mk(ValueFunction, sd_r, vm), H, obs, act, **kw)).cuda()
+    cguide = ValueGuide(ValueDiffusion(mk(ValueFunction, sd_c, vm), H, obs, act, **kw)).cuda()
+    idx = torch.arange(total, device='cuda') % Bg
+    noise = torch.from_numpy(fx['noise']).cuda()[:, idx].contiguous()
+    cond = {0: torch.from_numpy(fx['cond0']).cuda()[None].repeat(total, 1)}
+    thr = torch.full((total,), float(fx['cost_threshold']), device='cuda')
+    x, v, c, _ = diff.sample_raw((total, H, D), cond, sample_fn=fn, noise=noise, guide=guide, cost_guide=cguide,
+                                 cost_threshold=thr, **fixture_kwargs(fx))
+    torch.cuda.synchronize()
+    gx = fx['constrained_chain'][:, -1]
+    err = rel_err(x.cpu().numpy(), gx[idx.cpu().numpy()])
+    print('bf16x3 20-step chain error vs reference:', err)
+    assert err < CHAIN_TOL
+    np.testing.assert_allclose(np.sort(c[:Bg].cpu().numpy()), np.sort(fx['constrained_costs']), rtol=0, atol=CHAIN_TOL)
+
+
+def test_training_gradients_bf16x3():
+    import trebi_oracle as O
+    import trebi_train_oracle as TO
+    from diffuser.models import TemporalUnet, GaussianDiffusion
+    fx = np.load(os.path.join(GOLDEN, 'train_halfcheetah.npz'))
+    obs, act, H, T = int(fx['obs']), int(fx['act']), int(fx['H']), int(fx['T'])
+    mults = tuple(int(m) for m in fx['mults'])
+    D = obs + act
+    sd = synth.synth_state_dict(spec.unet_param_shapes(H, D, int(fx['dim']), mults), int(fx['seed_w']))
+    unet = TemporalUnet(H, D, 0, dim=int(fx['dim']), dim_mults=mults)
+    unet.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    diff = GaussianDiffusion(unet, H, obs, act, n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False,
+                             action_weight=float(fx['action_weight'])).cuda()
+    eng = diff.train_engine(max_batch=8)
+    eng.set_precision('bf16x3', min_batch=1)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    loss, _ = diff.p_losses(cu(fx['s0m0_x']), {0: cu(fx['s0m0_c'])}, cu(fx['s0m0_t']), noise=cu(fx['s0m0_n']))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(fx['s0m0_loss'])) <= 1e-3 * abs(float(fx['s0m0_loss']))
+    lw = TO.loss_weights(H, D, act, float(fx['action_weight']))
+    _, _, og = TO.p_losses(TO.TrainableUnet(sd, H, D, int(fx['dim']), mults), fx['s0m0_x'], {0: fx['s0m0_c']}, fx['s0m0_t'],
+                           fx['s0m0_n'], lw, act, O.make_schedule(T))
+    g = eng.grads.detach().cpu().numpy()
+    off, worst = 0, 0.0
+    for k, shape in unet._shapes.items():
+        n = int(np.prod(shape))
+        ref = og[k].reshape(-1)
+        err = np.abs(g[off:off + n] - ref).max() / max(np.abs(ref).max(), 1e-12)
+        worst = max(worst, err)
+        assert err < GRAD_TOL, (k, err)
+        off += n
+    print('worst bf16x3 training-gradient error vs oracle:', worst)

@@ -16,6 +16,7 @@ def main():
     ap.add_argument('--accum', type=int, default=2)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--mults', default='1,2,4,8')
+    ap.add_argument('--precision', default='f32')
     a = ap.parse_args()
     from trebi_amd import spec, synth
     from trebi_amd.training import Trainer
@@ -30,6 +31,7 @@ def main():
     diff = GaussianDiffusion(unet, H, OBS, ACT, n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False,
                              action_weight=10.0).to(dev)
     tr = Trainer(diff, train_batch_size=a.batch, train_lr=2e-4, gradient_accumulate_every=a.accum)
+    tr.engine.set_precision(a.precision)
     g = torch.Generator(dev).manual_seed(0)
     data = []
     for _ in range(a.accum):
@@ -44,7 +46,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     fl = (tr.engine.flops() + tr.engine.flops(backward=True)) * a.batch * a.accum
-    print(f'batch {a.batch} x accum {a.accum}: {1e3 * dt:.2f} ms per optimiser step, {a.batch * a.accum / dt:.0f} samples/s, '
+    print(f'{a.precision} batch {a.batch} x accum {a.accum}: {1e3 * dt:.2f} ms per optimiser step, {a.batch * a.accum / dt:.0f} samples/s, '
           f'{fl / dt / 1e12:.1f} TFLOP/s algorithmic ({100 * fl / dt / 157.3e12:.1f} % of fp32 MFMA peak); '
           f'fwd {tr.engine.flops() / 1e6:.2f} + bwd {tr.engine.flops(backward=True) / 1e6:.2f} MFLOP/sample; '
           f'loss {float(losses[-1][0]):.4f}')
