@@ -31,6 +31,7 @@ H, T, OBS, ACT, DIM = 32, 20, 17, 6, 32
 MULTS = (1, 2, 4, 8)
 PLAN_KW = dict(scale=0.001, t_stopgrad=4, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 matrix peak (no sparsity)
 
 
 def build_models(device):
@@ -112,10 +113,30 @@ def other_configs(device, steps=3, world=1, rank=0, rehearse=False):
             dt = float(td)
         fl = T * (unet.flops() + 2 * kw['n_guide_steps'] * (guide._net().flops() + guide._net().flops(backward=True)))
         tf = fl * n_global / dt / 1e12
-        out.append({'workload': f'{name}: {n_global} candidates over {world} GPU(s), {B} on this rank',
-                    'trajectories_per_s': n_global / dt, 'ms_per_step': 1e3 * dt, 'scaling': 'strong' if world > 1 else 'per-GPU size',
-                    'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS * world, 'unit': 'TFLOP/s',
-                    'frac': tf / (PEAK_F32_MFMA_TFLOPS * world)})
+        entry = {'workload': f'{name}: {n_global} candidates over {world} GPU(s), {B} on this rank',
+                 'trajectories_per_s': n_global / dt, 'ms_per_step': 1e3 * dt, 'scaling': 'strong' if world > 1 else 'per-GPU size',
+                 'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS * world, 'unit': 'TFLOP/s',
+                 'frac': tf / (PEAK_F32_MFMA_TFLOPS * world)}
+        # the same call with the opt-in bf16x3 operands (engaged from 512 candidates per launch up), reported apart
+        for net in (unet, guide._net(), cguide._net()):
+            net.set_precision('bf16x3')
+        run()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        fence()
+        dt = (time.perf_counter() - t0) / steps
+        if world > 1:
+            td = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            dt = float(td)
+        tf = fl * n_global / dt / 1e12
+        entry['bf16x3'] = {'trajectories_per_s': n_global / dt, 'ms_per_step': 1e3 * dt, 'achieved': tf,
+                           'peak': PEAK_BF16_MFMA_TFLOPS * world, 'unit': 'TFLOP/s (algorithmic)',
+                           'frac': tf / (PEAK_BF16_MFMA_TFLOPS * world),
+                           'frac_of_f32_matrix_peak': tf / (PEAK_F32_MFMA_TFLOPS * world)}
+        out.append(entry)
         del planner, diff, guide, cguide, unet
         torch.cuda.empty_cache()
     return out
@@ -137,8 +158,24 @@ def unet_utilisation(unet, device, batch=8192, iters=10):
     torch.cuda.synchronize(device)
     ms = e0.elapsed_time(e1) / iters
     tf = unet.flops() * batch / (ms * 1e-3) / 1e12
-    return {'workload': f'TemporalUnet forward alone, {batch} candidates, dim_mults {tuple(MULTS)}', 'ms': ms,
-            'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F32_MFMA_TFLOPS}
+    out = {'workload': f'TemporalUnet forward alone, {batch} candidates, dim_mults {tuple(MULTS)}', 'ms': ms,
+           'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F32_MFMA_TFLOPS}
+    # the opt-in bf16x3 operand mode (3 bf16 MFMAs per product, fp32 accumulate; 6e-5 of the reference), reported apart:
+    # algorithmic FLOPs (one per multiply-add, not three) against the bf16 dense matrix peak
+    unet.set_precision('bf16x3')
+    for _ in range(2):
+        unet(x, None, t)
+    e0.record()
+    for _ in range(iters):
+        unet(x, None, t)
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / iters
+    tf = unet.flops() * batch / (ms * 1e-3) / 1e12
+    out['bf16x3'] = {'ms': ms, 'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s (algorithmic; 3 bf16 MFMA flops each)',
+                     'frac': tf / PEAK_BF16_MFMA_TFLOPS, 'frac_of_f32_matrix_peak': tf / PEAK_F32_MFMA_TFLOPS}
+    unet.set_precision('f32')
+    return out
 
 
 def train_step_extra(device, world, rank, batch=4096, accum=2, steps=4, cpu=True):
@@ -189,6 +226,22 @@ def train_step_extra(device, world, rank, batch=4096, accum=2, steps=4, cpu=True
            'peak': PEAK_F32_MFMA_TFLOPS * world, 'unit': 'TFLOP/s', 'frac': fl / dt / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
            'algorithmic_mflop_per_sample': {'forward': tr.engine.flops() / 1e6, 'backward': tr.engine.flops(backward=True) / 1e6},
            'loss': float(losses[-1][0]), 'scaling': 'strong', 'dtype': 'f32'}
+    tr.engine.set_precision('bf16x3')          # opt-in operands for the forward / input-gradient convolutions, reported apart
+    for _ in range(2):
+        tr.train_step(data, global_batch_sizes=sizes)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(data, global_batch_sizes=sizes)
+    fence()
+    dtb = (time.perf_counter() - t0) / steps
+    if world > 1:
+        td = torch.tensor([dtb], device=device, dtype=torch.float64)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dtb = float(td)
+    out['bf16x3'] = {'samples_per_s': batch * accum / dtb, 'ms_per_optimiser_step': 1e3 * dtb, 'achieved': fl / dtb / 1e12,
+                     'unit': 'TFLOP/s (algorithmic)', 'frac_of_f32_matrix_peak': fl / dtb / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+                     'note': 'forward and input-gradient convolutions on bf16x3 operands; weight gradients, loss, Adam, EMA fp32'}
     if cpu and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         import trebi_train_oracle as TO
