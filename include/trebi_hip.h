@@ -109,6 +109,11 @@ size_t trebi_unet_workspace_bytes(const trebi_net* net, int B);
 int trebi_unet_forward(trebi_net* net, const float* x, int ldx, const int64_t* t, float* out,
                        int ldo, int B, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Parity tap (no counterpart in the reference; its tests would use forward hooks): after trebi_unet_forward on a
+ * batch of B, the output of the ResidualTemporalBlock `block` ("downs.0.0", "mid_block2", "ups.1.1", ...;
+ * temporal.py:18-46) is the channels-last tensor [B, L, ld] (first C columns) at workspace + offset_floats. */
+int trebi_unet_tap(const trebi_net* net, const char* block, int B, size_t* offset_floats, int* L, int* C, int* ld);
+
 /* trebi_unet_forward with NO workspace argument and no allocation of any kind: the
  * activations go to a static per-GPU device array of TREBI_STATIC_SCRATCH_BYTES that the
  * library's code object carries (every GPU the library runs on holds it until the process

@@ -1752,6 +1752,25 @@ extern "C" size_t trebi_value_workspace_bytes(const trebi_net* net, int B) {
   return net && B > 0 ? net->ws_floats(B) * sizeof(float) : 0;
 }
 
+// Where the output of a named ResidualTemporalBlock sits in the workspace after trebi_unet_forward (parity taps).
+extern "C" int trebi_unet_tap(const trebi_net* net, const char* block, int B, size_t* offset_floats, int* L, int* C,
+                              int* ld) {
+  if (!net || !block || !offset_floats || !L || !C || !ld || B < 1) return fail(TREBI_BAD_ARG, "null argument");
+  if (net->desc.kind != 0) return fail(TREBI_BAD_ARG, "not a TemporalUnet");
+  const UnetRec& rec = net->rec;
+  std::vector<const RBInfo*> all{&rec.mid1, &rec.mid2};
+  for (auto* v : {&rec.down0, &rec.down1, &rec.up0, &rec.up1})
+    for (auto& r : *v) all.push_back(&r);
+  for (const RBInfo* r : all)
+    if (r->prefix == block) {
+      if (r->dst.id < 0) return fail(TREBI_BAD_ARG, "block '%s' writes to a caller tensor, not the workspace", block);
+      *offset_floats = net->offsets(B)[r->dst.id] + r->dst.coloff;
+      *L = r->L; *C = r->cout; *ld = r->dst.ld;
+      return 0;
+    }
+  return fail(TREBI_BAD_ARG, "no ResidualTemporalBlock named '%s'", block);
+}
+
 extern "C" int trebi_unet_forward(trebi_net* net, const float* x, int ldx, const int64_t* t, float* out, int ldo,
                                   int B, void* ws, size_t ws_bytes, void* stream) {
   if (!net || !x || !t || !out || !ws) return fail(TREBI_BAD_ARG, "null argument");

@@ -54,6 +54,8 @@ SIGNATURES = {
     'trebi_net_flops': (C.c_double, [_VP, C.c_int]),
     'trebi_unet_workspace_bytes': (C.c_size_t, [_VP, C.c_int]),
     'trebi_unet_forward': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    'trebi_unet_tap': (C.c_int, [_VP, C.c_char_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int)]),
     'trebi_unet_forward_static': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int, C.c_int, _VP]),
     'trebi_value_workspace_bytes': (C.c_size_t, [_VP, C.c_int]),
     'trebi_value_gradients': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t,

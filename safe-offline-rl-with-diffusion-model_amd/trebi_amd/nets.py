@@ -227,6 +227,17 @@ class TemporalUnet(_HipNet):
         return out
 
 
+    def tap(self, block, B):
+        """Output of the ResidualTemporalBlock `block` ('downs.0.0', 'mid_block2', ...) left in the workspace by the last
+        forward on a batch of B: a [B, L, C] view (channels-last; the reference's hooks see [B, C, L])."""
+        dev = next(self.parameters()).device
+        ws = self._ws[(B, str(dev))].view(torch.float32)
+        off, L, Cc, ld = C.c_size_t(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(_lib.lib().trebi_unet_tap(self.net_handle(dev), block.encode(), B, C.byref(off), C.byref(L), C.byref(Cc),
+                                             C.byref(ld)))
+        return ws[off.value:off.value + B * L.value * ld.value].view(B, L.value, ld.value)[:, :, :Cc.value]
+
+
 class ValueFunction(_HipNet):
     _kind = 1
 

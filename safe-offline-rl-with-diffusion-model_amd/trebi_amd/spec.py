@@ -9,7 +9,7 @@ reference's ``state_dict()`` keys so that a reference ``state_{epoch}.pt``
 * ValueFunction  -- /root/reference/diffuser/models/temporal.py:153-211
 * block internals -- temporal.py:18-46, helpers.py:30-63
 
-The HIP library (csrc/plan.cpp) derives the same plan from the same five
+The HIP library (csrc/trebi.hip, make_arch / param_specs) derives the same plan from the same five
 integers; tests/test_host.py checks that the two agree on every name.
 """
 from collections import OrderedDict

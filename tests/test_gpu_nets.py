@@ -40,6 +40,21 @@ def test_unet_forward_golden(setup):
         assert rel_err(out, fx[f'unet_out_t{tt}']) < TOL, tt
 
 
+def test_unet_taps_golden(setup):
+    """Intermediate activations the reference's forward hooks captured (make_golden.py: output of downs.0.0 and of
+    mid_block2 at t = 5) against the HIP path's workspace, not only against the oracle."""
+    fx, unet, _, _, _ = setup
+    if 'unet_tap_down0_block0_t5' not in fx:
+        pytest.skip('fixture has no taps')
+    B = int(fx['B'])
+    x = torch.from_numpy(fx['net_x']).cuda()
+    unet(x, None, torch.full((B,), 5, device='cuda', dtype=torch.long))
+    for block, key in (('downs.0.0', 'unet_tap_down0_block0_t5'), ('mid_block2', 'unet_tap_mid_out_t5')):
+        got = unet.tap(block, B).permute(0, 2, 1).cpu().numpy()          # [B, C, L] like the reference
+        assert got.shape == fx[key].shape, (block, got.shape, fx[key].shape)
+        assert rel_err(got, fx[key]) < TOL, block
+
+
 def test_value_gradients_golden(setup):
     fx, _, rnet, cnet, _ = setup
     B = int(fx['B'])

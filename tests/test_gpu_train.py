@@ -195,3 +195,54 @@ def test_full_size_batch_through_linearity(name, total):
         assert err < 1e-3, (k, err)
         off += n
     assert float(scale) > 0
+
+
+class _TinyDataset(torch.utils.data.Dataset):
+    """What SequenceDataset hands the loop (datasets/sequence.py: Batch(trajectories, conditions)), as plain tuples."""
+
+    def __init__(self, fx, n):
+        obs, act, H = int(fx['obs']), int(fx['act']), int(fx['H'])
+        self.x = synth.synth_normal(11, 'tiny.x', (n, H, obs + act))
+        self.act = act
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, i):
+        return self.x[i], {0: self.x[i, 0, self.act:]}
+
+
+def test_trainer_loop_with_a_dataloader_and_checkpoint_round_trip(tmp_path):
+    """Trainer.train over a DataLoader (training.py:104-139: ragged last batch, CPU batches, save at step 0) and
+    save -> load into a second Trainer (training.py:141-166): same weights, and the kernels run on the loaded ones."""
+    from trebi_amd.training import Trainer
+    fx = np.load(os.path.join(GOLDEN, 'train_halfcheetah.npz'))
+    diff, sd = _model(fx)
+    ds = _TinyDataset(fx, 20)                                                  # batches of 8, 8, 4
+    tr = Trainer(diff, ds, train_batch_size=8, train_lr=1e-3, gradient_accumulate_every=2, step_start_ema=1,
+                 update_ema_every=1, save_freq=1000, log_freq=1, results_folder=str(tmp_path))
+    tr.train(3)
+    torch.cuda.synchronize()
+    assert tr.step == 3 and tr.adam_steps == 3
+    assert os.path.exists(tmp_path / 'state_0.pt')                              # step 0 % save_freq == 0
+    moved = max(float((v.detach().cpu() - torch.from_numpy(sd[k])).abs().max()) for k, v in tr.model.model.state_dict().items())
+    assert 1e-4 < moved < 4e-3                                                  # three Adam steps of about lr each
+    path = tr.save(7)
+    saved = torch.load(path, map_location='cpu', weights_only=True)
+    assert set(saved) == {'step', 'model', 'ema'} and saved['step'] == 3
+    assert set(saved['model']) == set(tr.model.state_dict())                    # the reference's key set
+
+    diff2, _ = _model(fx, seed=99)                                              # other weights, then load
+    tr2 = Trainer(diff2, train_batch_size=8, train_lr=1e-3, gradient_accumulate_every=2, results_folder=str(tmp_path))
+    tr2.load(7)
+    assert tr2.step == 3
+    for a, b in ((tr.model, tr2.model), (tr.ema_model, tr2.ema_model)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    x, cond, t, noise = _batch(fx, 0, 0)
+    la, _ = tr.model.p_losses(x, cond, t, noise=noise)
+    lb, _ = tr2.model.p_losses(x, cond, t, noise=noise)
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))                  # training kernels see the loaded weights
+    ga, gb = tr.engine.grads, tr2.engine.grads            # (column sums go through LDS atomics: not bit-reproducible)
+    assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max())
+    assert torch.equal(tr.ema_model.model(x, None, t), tr2.ema_model.model(x, None, t))   # and so does the planning path
