@@ -60,6 +60,7 @@ struct ConvGeo {
   int S, NG, KS, nthr;                            // nthr = 64*NG*KS threads work in this stage
   int TM, TN, TNp;
   int R, ldA, ld2, cbpt, KK1, KK, chunk;
+  int CS, CS2;                                    // candidate stride of slab / slab2 in floats (padded, see conv_make_geo)
   int nv, vlo, fh, hr;                            // valid input rows [vlo, vlo+nv) per candidate, front / total halo rows
   int pm, fhk;                                    // position-major tiles (see Tile::pm): flag, front halo of the K loop
   int resg;                                       // identity residual read from global memory in the epilogue (no LDS tile)
@@ -79,7 +80,7 @@ struct ConvLaunch {
 // One stage of a resident chain: consecutive layers whose workgroups own whole candidates AND all output
 // columns run in ONE launch; a layer's output stays in LDS for the layers that consume it (it is also
 // written to global memory when something outside the chain reads it).  Resident tensors use one canonical
-// LDS layout: per candidate (L + 4) rows of ld = C + 4 floats, two zero halo rows in front and behind.
+// LDS layout: per candidate (L + 4) rows of ld = C + 8 floats, two zero halo rows in front and behind.
 // All offsets are in floats from the start of dynamic LDS.  The table lives in device memory.
 struct RStage {
   ConvP p[2];

@@ -1328,7 +1328,7 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
       st.resRes = lr != nullptr;
       st.RbR = lr ? op.Lout + 4 : op.Lout;
       st.hR = lr ? 2 : 0;
-      st.ldR = lr ? op.N + 4 : G.TNp;
+      st.ldR = lr ? op.N + 8 : G.TNp;
       const int reg_s = ls ? ls->region : -1, reg_2 = l2 ? l2->region : -1, reg_r = lr ? lr->region : -1;
       const bool have_s = ls != nullptr, have_2 = l2 != nullptr, have_r = lr != nullptr;
       if (st.a0 < 0 || (!st.vec && op.pro)) { run.clear(); break; }
@@ -1366,10 +1366,10 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
           live.push_back({kd, reg, last, Ld});
           st.dstRes = 1;
           st.oD = reg;                                   // region index for now, offset below
-          st.RbD = Ld + 4; st.ldD = Cd + 4; st.Ld = Ld;
+          st.RbD = Ld + 4; st.ldD = Cd + 8; st.Ld = Ld;   // row stride as conv_make_geo's ldA (bank rule there)
           st.mLd4 = st.ldD / 4 > 1 ? 0xFFFFFFFFu / (unsigned)(st.ldD / 4) + 1u : 0u;
           nreg = std::max(nreg, reg + 1);
-          regsz = std::max(regsz, (size_t)S * (Ld + 4) * (Cd + 4));
+          regsz = std::max(regsz, (size_t)S * (Ld + 4) * (Cd + 8));
         } else {
           need_global = true;
         }

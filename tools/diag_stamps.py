@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'safe-offline-rl-with-diffusion-model_amd'))
 import numpy as np, torch
 from trebi_amd import _lib, spec, synth
-_lib.LIB_PATH = os.path.join(ROOT, 'tools', 'dbg', 'libtrebi_hip.so')
+_lib.LIB_PATH = os.environ.get('TREBI_DBG_LIB') or os.path.join(ROOT, 'tools', 'dbg', 'libtrebi_hip.so')
 from trebi_amd.nets import TemporalUnet, ValueFunction
 H, D, B = 32, 23, int(sys.argv[1]) if len(sys.argv) > 1 else 64
 kind = sys.argv[2] if len(sys.argv) > 2 else 'value'
@@ -20,7 +20,7 @@ lib = _lib.lib()
 lib.trebi_debug_read_stamps.argtypes = [C.POINTER(C.c_uint64)]
 buf = (C.c_uint64 * 32)()
 run = (lambda: net.value_and_input_grad(x, t)) if kind == 'value' else (lambda: net(x, None, t))
-nops = 60 if kind == 'value' else 45
+nops = int(sys.argv[3]) if len(sys.argv) > 3 else (60 if kind == 'value' else 45)
 print('op  total_cyc  us(100MHz clk)  clkGHz | phases: preload stage wait_bar prologue kloop bar+partials epilogue')
 for n in range(nops):
     os.environ['TREBI_STOP_AFTER'] = str(n)
