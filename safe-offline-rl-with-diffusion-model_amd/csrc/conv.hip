@@ -21,6 +21,7 @@
 // (ConvGeo), kernel-argument fields are read once and pinned in scalar registers, everything moves
 // in float4, and layers whose workgroups are independent are chained inside one launch
 // (conv_chain_kernel) with a workgroup barrier instead of a kernel boundary.
+#include <type_traits>
 #include "device_util.h"
 
 namespace trebi {
@@ -734,54 +735,98 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
     const float icnt = 1.f / (float)(cnt4 * 4);
     float* sy = CP(save_y);
     float* sg = CP(save_g);
-    for (int inst = team; inst < ninst; inst += nteams) {
-      int s = dGpt.div(inst), gi = inst - s * gpt;
-      if (s >= nvs) continue;
-      const int tbase = s * Lout * TNp + gi * gch;
-      float sum = 0.f;
-#pragma unroll 2
-      for (int e = tl; e < cnt4; e += ts) {
-        int lo = dG.div(e), c = 4 * (e - lo * g4), o = tbase + lo * TNp + c;
-        f32x4 v = *(const f32x4*)&colp[gi * gch + c];
-        for (int k = 0; k < KS; ++k) v += *(const f32x4*)&red[k * kstride + o];
-        *(f32x4*)&red[o] = v;
-        sum += hsum(v);
-      }
-      const float mean = team_sum(sum, ts) * icnt;
-      float sq = 0.f;
-#pragma unroll 2
-      for (int e = tl; e < cnt4; e += ts) {
-        int lo = dG.div(e), o = tbase + lo * TNp + 4 * (e - lo * g4);
-        f32x4 d = *(const f32x4*)&red[o] - mean;
-        sq += hsum(d * d);
-      }
-      const float rstd = 1.f / sqrtf(team_sum(sq, ts) * icnt + GN_EPS);
-      if (tl == 0 && CP(save_stats)) {
-        float* o = CP(save_stats) + ((unsigned)(b0 + s) * GN_GROUPS + (n0 / gch + gi)) * 2;
-        gst(o, mean);
-        gst(o + 1, rstd);
-      }
-      for (int e = tl; e < cnt4; e += ts) {
-        int lo = dG.div(e), col = gi * gch + 4 * (e - lo * g4), row = s * Lout + lo;
-        f32x4 xh = (*(const f32x4*)&red[row * TNp + col] - mean) * rstd;
-        f32x4 ga = *(const f32x4*)&colp[TN + col];
-        f32x4 z = xh * ga + *(const f32x4*)&colp[2 * TN + col];
-        f32x4 m, dm;
+    // Two (candidate, group) instances per trip: the three passes of one instance are a dependent chain (LDS read ->
+    // cross-lane sum -> LDS read ...) with two float4 per lane at most, so a second, independent instance fills the gaps.
+    // A slot without an instance repeats the first one (same values to the same addresses) and skips the global stores.
+    // (Small batches have one instance per team: they take the one-slot form, a repeated slot would double their work.)
+    const bool want_dm = sg != nullptr;
+    auto gn_epilogue = [&](auto iu_tag) {
+    constexpr int IU = decltype(iu_tag)::value;
+    for (int inst0 = team; inst0 < ninst; inst0 += IU * nteams) {
+      int s_[IU], gi_[IU], tbase_[IU];
+      bool on_[IU];
+      float mean_[IU], rstd_[IU];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float a, b;
-          mish_both(z[q], &a, &b);
-          m[q] = a;
-          dm[q] = b;
+      for (int q = 0; q < IU; ++q) {
+        int inst = inst0 + q * nteams;
+        on_[q] = inst < ninst;
+        inst = on_[q] ? inst : inst0;
+        s_[q] = dGpt.div(inst);
+        gi_[q] = inst - s_[q] * gpt;
+        on_[q] = on_[q] && s_[q] < nvs;
+        tbase_[q] = s_[q] * Lout * TNp + gi_[q] * gch;
+      }
+      float sum_[IU] = {};
+#pragma unroll 2
+      for (int e = tl; e < cnt4; e += ts) {
+        const int lo = dG.div(e), c = 4 * (e - lo * g4);
+#pragma unroll
+        for (int q = 0; q < IU; ++q) {
+          const int o = tbase_[q] + lo * TNp + c;
+          f32x4 v = *(const f32x4*)&colp[gi_[q] * gch + c];
+          for (int k = 0; k < KS; ++k) v += *(const f32x4*)&red[k * kstride + o];
+          if (q == 0 || on_[q]) *(f32x4*)&red[o] = v;
+          sum_[q] += hsum(v);
         }
-        if (sy) {
-          unsigned so = ((unsigned)b0 * Lout + row) * (unsigned)N + n0 + col;
-          gst4(sy + so, xh);
-          if (sg) gst4(sg + so, dm * ga);          // training keeps xhat only (train.hip recomputes mish')
+      }
+#pragma unroll
+      for (int q = 0; q < IU; ++q) mean_[q] = team_sum(sum_[q], ts) * icnt;
+      float sq_[IU] = {};
+#pragma unroll 2
+      for (int e = tl; e < cnt4; e += ts) {
+        const int lo = dG.div(e), c = 4 * (e - lo * g4);
+#pragma unroll
+        for (int q = 0; q < IU; ++q) {
+          f32x4 d = *(const f32x4*)&red[tbase_[q] + lo * TNp + c] - mean_[q];
+          sq_[q] += hsum(d * d);
         }
-        finish(m, s, row, col);
+      }
+#pragma unroll
+      for (int q = 0; q < IU; ++q) rstd_[q] = 1.f / sqrtf(team_sum(sq_[q], ts) * icnt + GN_EPS);
+      if (tl == 0 && CP(save_stats)) {
+#pragma unroll
+        for (int q = 0; q < IU; ++q)
+          if (on_[q]) {
+            float* o = CP(save_stats) + ((unsigned)(b0 + s_[q]) * GN_GROUPS + (n0 / gch + gi_[q])) * 2;
+            gst(o, mean_[q]);
+            gst(o + 1, rstd_[q]);
+          }
+      }
+      for (int e = tl; e < cnt4; e += ts) {
+        const int lo = dG.div(e), c = 4 * (e - lo * g4);
+#pragma unroll
+        for (int q = 0; q < IU; ++q) {
+          const int col = gi_[q] * gch + c, row = s_[q] * Lout + lo;
+          f32x4 xh = (*(const f32x4*)&red[row * TNp + col] - mean_[q]) * rstd_[q];
+          f32x4 ga = *(const f32x4*)&colp[TN + col];
+          f32x4 z = xh * ga + *(const f32x4*)&colp[2 * TN + col];
+          f32x4 m, dm;
+          if (want_dm) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float a, b;
+              mish_both(z[j], &a, &b);
+              m[j] = a;
+              dm[j] = b;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = mish_f(z[j]);
+          }
+          if (on_[q]) {
+            if (sy) {
+              unsigned so = ((unsigned)b0 * Lout + row) * (unsigned)N + n0 + col;
+              gst4(sy + so, xh);
+              if (want_dm) gst4(sg + so, dm * ga);          // training keeps xhat only (train.hip recomputes mish')
+            }
+            finish(m, s_[q], row, col);
+          }
+        }
       }
     }
+    };
+    if (ninst > nteams) gn_epilogue(std::integral_constant<int, 2>{});
+    else gn_epilogue(std::integral_constant<int, 1>{});
   } else {
     const int nitems = CG(nRes4);            // TM * TN / 4
     for (int e = tid; e < nitems; e += nthr) {
