@@ -684,7 +684,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
     const int lrows = Lout < 16 ? Lout : 16;           // rows of a candidate inside this wave's tile
     const int gl = gch < 16 ? gch : 16;                // columns of a group inside a 16-column tile
     if (hasgn && active) {
-      const float inl = 1.f / (float)(lrows * gl);
+      const float inl = fast_rcp((float)(lrows * gl));      // a power of two: exact, without the IEEE division sequence
       // per-q partials -> per-q totals over this wave's part of the (candidate, group)
       auto reduce = [&](float (&t)[4]) {
         if (Lout >= 4) {
@@ -743,7 +743,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (hasgn && (q == 0 || Lout < 4)) {
-            float M2 = m2[ni][q], cnt = (float)(lrows * gl);
+            float M2 = m2[ni][q], cnt = (float)(lrows * gl), icnt = fast_rcp(cnt);     // powers of two
             mean = ml[ni][q];
             if (xchg) {                                  // Chan's combination of two equal-sized parts
               const int pwv = two ? ((ks & 1) ? wave - NG : wave + NG) : (wave ^ 1);
@@ -753,8 +753,9 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
               M2 = M2 + m2p + dlt * dlt * (0.5f * cnt);
               mean = 0.5f * (mean + mp);
               cnt *= 2.f;
+              icnt *= 0.5f;
             }
-            rstd = __frsqrt_rn(M2 / cnt + GN_EPS);
+            rstd = __frsqrt_rn(M2 * icnt + GN_EPS);
           }
           if (!vq[q]) continue;
           const int sw = sq[q], lo = loq[q];
@@ -766,12 +767,13 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
               gst(o + 1, rstd);
             }
             const float xh = (val - mean) * rstd;
-            float a, b;
-            mish_both(xh * dgam[ni] + dbet[ni], &a, &b);
+            float a, b = 0.f;
+            if (sg) mish_both(xh * dgam[ni] + dbet[ni], &a, &b);
+            else a = mish_f(xh * dgam[ni] + dbet[ni]);
             if (sy && col < N) {
               const unsigned so = ((unsigned)(b0 + sw) * Lout + lo) * (unsigned)N + col;
               gst(sy + so, xh);
-              gst(sg + so, b * dgam[ni]);
+              if (sg) gst(sg + so, b * dgam[ni]);
             }
             val = a;
           }
@@ -871,7 +873,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
           f32x4 d = v[j] - mean;
           sq += hsum(d * d);
         }
-      const float rstd = 1.f / sqrtf(team_sum(sq, ts) * icnt + GN_EPS);
+      const float rstd = __frsqrt_rn(team_sum(sq, ts) * icnt + GN_EPS);
       if (tl == 0 && DP(save_stats)) {
         float* o = DP(save_stats) + ((unsigned)(b0 + s) * GN_GROUPS + gi) * 2;
         gst(o, mean);

@@ -782,7 +782,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
         }
       }
 #pragma unroll
-      for (int q = 0; q < IU; ++q) rstd_[q] = 1.f / sqrtf(team_sum(sq_[q], ts) * icnt + GN_EPS);
+      for (int q = 0; q < IU; ++q) rstd_[q] = __frsqrt_rn(team_sum(sq_[q], ts) * icnt + GN_EPS);
       if (tl == 0 && CP(save_stats)) {
 #pragma unroll
         for (int q = 0; q < IU; ++q)
