@@ -267,6 +267,12 @@ hipError_t launch_add_cols(float* dst, int ldd, const float* src, int lds, long 
 // =====================================================================================================
 // weight gradient GEMM
 // =====================================================================================================
+#ifdef TREBI_STAMPS          // diagnostic build only: phase cycles of workgroup (0,0), thread 0 of the last wgrad launch
+__device__ unsigned long long g_wstamps[16];
+extern "C" int trebi_debug_read_wstamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamps), sizeof(g_wstamps));
+}
+#endif
 template <int NB>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {      // two workgroups per CU: at most 256 VGPRs
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -354,11 +360,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {      // two work
     }
   };
   const bool pf = p.pf != 0;
+#ifdef TREBI_STAMPS
+  unsigned long long tq0 = __builtin_amdgcn_s_memtime(), tq_commit = 0, tq_bar = 0, tq_fetch = 0, tq_mma = 0, tq1, tq2;
+#define WQ(acc) { tq2 = __builtin_amdgcn_s_memtime(); acc += tq2 - tq1; tq1 = tq2; }
+#else
+#define WQ(acc)
+#endif
   if (pf && s_begin < s_end) fetch(s_begin);
+#ifdef TREBI_STAMPS
+  tq1 = __builtin_amdgcn_s_memtime();
+#endif
   for (int s0 = s_begin; s0 < s_end; s0 += S) {
     if (pf) commit(); else stage_sync(s0);
+    WQ(tq_commit)
     __syncthreads();
+    WQ(tq_bar)
     if (pf && s0 + S < s_end) fetch(s0 + S);
+    WQ(tq_fetch)
     // ---- MFMA: k-slot g of an instruction = candidate 4*sq + g, all four at the same position ----
     const float* aw = As + g * SA + wave * 16 + lr;
     const float* bw = Bs + g * SB + lr;
@@ -382,8 +400,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {      // two work
         }
       }
     }
+    WQ(tq_mma)
     __syncthreads();
+    WQ(tq_bar)
   }
+#ifdef TREBI_STAMPS
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    g_wstamps[0] = tq_commit; g_wstamps[1] = tq_bar; g_wstamps[2] = tq_fetch; g_wstamps[3] = tq_mma;
+    g_wstamps[4] = __builtin_amdgcn_s_memtime() - tq0; g_wstamps[5] = (unsigned long long)((s_end - s_begin + S - 1) / S);
+    g_wstamps[6] = (unsigned long long)S; g_wstamps[7] = (unsigned long long)LB; g_wstamps[8] = (unsigned long long)(NB * 100 + p.nwa * 10 + k);
+    g_wstamps[9] = (unsigned long long)p.CA16 * 10000 + p.CB16;
+  }
+#endif
   // ---- partial tile -> slab[ks][tap][cb][ca]: D[i][j]: lane holds rows i = 4g..4g+3 (ca), column j = lr (cb) ----
   float* out = p.slab + (size_t)blockIdx.y * p.slab_stride;
 #pragma unroll

@@ -572,6 +572,15 @@ extern "C" int trebi_trainer_accumulate(trebi_trainer* tr, const float* x_start,
         w.mLB = t.LB > 1 ? 0xFFFFFFFFu / (unsigned)t.LB + 1u : 0u;
         if (!w.A || !w.Bm) return fail(TREBI_HIP_ERROR, "internal: unresolved operand at %s", t.name.c_str());
         HIPCHK(launch_wgrad(w, c.ksplit, st));
+#ifdef TREBI_STAMPS
+        if (getenv("TREBI_WGRAD_STAMPS")) {      // diagnostic build: phase cycles of workgroup (0,0), thread 0
+          unsigned long long sb[32];
+          (void)hipDeviceSynchronize();
+          (void)trebi_debug_read_wstamps(sb);
+          fprintf(stderr, "wgrad %-40s CA16xCB16 %llu NB/nwa/k %llu S %llu LB %llu chunks %llu ksplit %d | total %llu commit %llu barrier %llu fetch %llu mma %llu\n",
+                  t.name.c_str(), sb[9], sb[8], sb[6], sb[7], sb[5], c.ksplit, sb[4], sb[0], sb[1], sb[2], sb[3]);
+        }
+#endif
         HIPCHK(launch_wreduce(tr->wslab, c.ksplit, c.slab_stride, t.k, t.CA, t.CB, c.CA16, c.CB16, tr->grads + t.off_w, st));
         break;
       }

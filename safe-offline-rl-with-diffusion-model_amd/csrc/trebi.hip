@@ -2249,4 +2249,7 @@ extern "C" double trebi_net_flops(const trebi_net* net, int backward) {
 // ------------------------------------------------------------------------------------
 // the training step: host side
 // ------------------------------------------------------------------------------------
+#ifdef TREBI_STAMPS
+extern "C" int trebi_debug_read_wstamps(unsigned long long* out);
+#endif
 #include "trainer.inl"
