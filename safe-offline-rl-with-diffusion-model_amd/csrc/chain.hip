@@ -403,7 +403,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
   if (haspro) {
     const float* pin = smem + (DS(proRes) ? DS(oPro) : DS(oSrc));
     if (active) {
-      const float icnt = 1.f / (float)(DG(pcnt4) * 4);
+      const float icnt = DG(picnt);
       for (int inst = pteam; inst < S * GN_GROUPS; inst += pnteams) {
         if (inst != pteam) pinst = pro_fetch(inst, pg_, px_, po_, pi_, prstd);
         f32x4 d[2];
@@ -840,7 +840,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
     const int team = ts == 64 ? (tid >> 6) : (tid >> 4), tl = tid & (ts - 1),
               nteams = ts == 64 ? (nthr >> 6) : (nthr >> 4);
     const FastDiv dG(g4, DG(mGch4)), dGpt(gpt, DG(mGpt));
-    const float icnt = 1.f / (float)(cnt4 * 4);
+    const float icnt = DG(icnt);
     float* sy = DP(save_y);
     float* sg = DP(save_g);
     for (int inst = team; inst < ninst; inst += nteams) {

@@ -69,6 +69,7 @@ struct ConvGeo {
   int c4n, c4n2, nValid4, nHalo4, nX24, nRes4, tn4;   // float4 counts of the staged streams
   int gpt, cnt4, pcnt4, gch4, pgch4, ts_epi, ts_pro;  // GroupNorm teams (float4 granularity)
   int veco, vecr;                                 // output / identity residual are float4-addressable
+  float icnt, picnt;                              // 1 / elements of a GroupNorm instance (epilogue, prologue): no device division
   unsigned mLout, mTN4, mNv, mHr, mGch4, mPGch4, mGpt, mOs, mC4, mC4b, mNG, mCbpt, mTN;
 };
 

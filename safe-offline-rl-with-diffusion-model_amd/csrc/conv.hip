@@ -108,6 +108,8 @@ ConvGeo conv_make_geo(const ConvP& p, const Tile& tl) {
   g.pgch4 = p.pro ? p.pro_gch / 4 : 1;
   g.cnt4 = p.gn ? p.Lout * g.gch4 : 1;
   g.pcnt4 = p.pro ? p.Lin * g.pgch4 : 1;
+  g.icnt = 1.f / (float)(g.cnt4 * 4);
+  g.picnt = 1.f / (float)(g.pcnt4 * 4);
   g.ts_epi = (g.S * g.gpt * 4 <= nteams16) ? 64 : 16;
   g.ts_pro = (g.S * GN_GROUPS * 4 <= nteams16) ? 64 : 16;
   const int ophase = p.osplit > 0 ? 2 : 1;
@@ -423,7 +425,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
       const int team = ts == 64 ? (tid >> 6) : (tid >> 4), tl = tid & (ts - 1),
                 nteams = ts == 64 ? (nthr >> 6) : (nthr >> 4);
       const FastDiv dG(pg4, CG(mPGch4));
-      const float icnt = 1.f / (float)(cnt4 * 4);
+      const float icnt = CG(picnt);
       for (int inst = team; inst < ninst; inst += nteams) {
         int s = inst >> 3, gi = inst & 7;
         if (s >= nvs) continue;
@@ -732,7 +734,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
     const int team = ts == 64 ? (tid >> 6) : (tid >> 4), tl = tid & (ts - 1),
               nteams = ts == 64 ? (nthr >> 6) : (nthr >> 4);
     const FastDiv dG(g4, CG(mGch4)), dGpt(gpt, CG(mGpt));
-    const float icnt = 1.f / (float)(cnt4 * 4);
+    const float icnt = CG(icnt);
     float* sy = CP(save_y);
     float* sg = CP(save_g);
     // Two (candidate, group) instances per trip: the three passes of one instance are a dependent chain (LDS read ->

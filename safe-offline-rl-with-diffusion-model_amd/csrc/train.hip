@@ -130,6 +130,45 @@ __global__ __launch_bounds__(1024) void gnb_kernel(GnbP p) {
     const size_t row0 = (size_t)b * L;
     float s1 = 0.f, s2 = 0.f;
     f32x4 dga = {0.f, 0.f, 0.f, 0.f}, dbe = dga, dtb = dga, dbi = dga;
+    if (cnt4 <= 32) {
+      // at most two float4 per lane (every H = 32 shape): the gradient and xhat stay in registers for the second pass
+      // instead of being read from HBM again (5 -> 3 streams of B x L x C floats; the kernel is HBM-bound)
+      f32x4 dxr[2], xhr[2];
+      size_t off[2];
+      bool ev[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tl + 16 * u;
+        ev[u] = e < cnt4;
+        const int li = (ev[u] ? e : tl) / g4;
+        off[u] = row0 + li;
+        dxr[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        xhr[u] = dxr[u];
+        if (ev[u]) {
+          const f32x4 da = gld4(p.dA + off[u] * (size_t)p.ldA + c);
+          xhr[u] = gld4(p.xhat + off[u] * (size_t)C + c);
+          f32x4 dz;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dz[q] = da[q] * mish_grad_f(xhr[u][q] * ga[q] + be[q]);
+          dxr[u] = dz * ga;
+          s1 += hsum(dxr[u]);
+          s2 += hsum(dxr[u] * xhr[u]);
+          dga += dz * xhr[u];
+          dbe += dz;
+          dtb += da;
+        }
+      }
+      s1 += dpp_f<0xB1>(s1); s1 += dpp_f<0x4E>(s1); s1 += dpp_f<0x141>(s1); s1 += dpp_f<0x140>(s1);
+      s2 += dpp_f<0xB1>(s2); s2 += dpp_f<0x4E>(s2); s2 += dpp_f<0x141>(s2); s2 += dpp_f<0x140>(s2);
+      const float m1 = s1 * icnt, m2 = s2 * icnt;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (ev[u]) {
+          const f32x4 dy = (dxr[u] - m1 - xhr[u] * m2) * rstd;
+          dbi += dy;
+          gst4(p.dY + off[u] * (size_t)C + c, dy);
+        }
+    } else {
     for (int e = tl; e < cnt4; e += 16) {
       const int li = e / g4;
       const f32x4 da = gld4(p.dA + (row0 + li) * (size_t)p.ldA + c);
@@ -160,6 +199,7 @@ __global__ __launch_bounds__(1024) void gnb_kernel(GnbP p) {
       }
       dbi += dy;
       gst4(p.dY + (row0 + li) * (size_t)C + c, dy);
+    }
     }
     // column sums over the positions of this candidate: lanes with the same c4 hold different positions
 #pragma unroll
