@@ -120,7 +120,7 @@ int trebi_unet_tap(const trebi_net* net, const char* block, int B, size_t* offse
  * ends).  No counterpart in the reference; it exists for callers that cannot allocate or
  * size a workspace -- code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  Returns TREBI_WORKSPACE_TOO_SMALL when
- * trebi_unet_workspace_bytes(net, B) > TREBI_STATIC_SCRATCH_BYTES (about 75
+ * trebi_unet_workspace_bytes(net, B) > TREBI_STATIC_SCRATCH_BYTES (about 260
  * candidates for the halfcheetah H=32 (1,2,4,8) TemporalUnet).  Results are bit-identical to
  * trebi_unet_forward.  All calls on one GPU share that GPU's array: calls that overlap on
  * one GPU (two streams, two threads) race; serialise them. */
