@@ -501,8 +501,10 @@ def main():
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'traffic_note': 'bytes per conv_gemm_kernel launch leaving the L2s (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 '
-                                         '--pmc, profiles/): fabric traffic -- weights re-fetched by every XCD after each kernel '
-                                         'boundary, mostly served by the 256 MB Infinity Cache, not HBM',
+                                         '--pmc, profiles/): fabric traffic, mostly served by the 256 MB Infinity Cache, not HBM.  '
+                                         'Algorithmic ~1.3 MB (0.67 MB of weights for both nets + the candidate tile in and out); the '
+                                         'grid is column-tile-major so that a weight slice is fetched by ONE XCD, which makes each of '
+                                         'the 8 column tiles (8 XCDs, 8 L2s) read the 0.5 MB of input activations: ~0.7 + 8 x 0.5 MB',
                          'avg_launch_us': avg_us, 'launches_per_step': prof['gemm_launches'],
                          'algorithmic_flops_per_launch': flops_per_launch,
                          'eager_loop_ms': prof['loop_us'] / 1e3},
