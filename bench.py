@@ -34,6 +34,24 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 matrix peak (no sparsity)
 
 
+def _coll_device(device):
+    """Tensors of the bench's own tiny collectives: on the GPU for RCCL (it needs device tensors), on the host for gloo
+    (the one-GPU rehearsal; gloo's device-tensor path stalled intermittently with two processes on one GPU)."""
+    return device if dist.get_backend() == 'nccl' else torch.device('cpu')
+
+
+def _max_over_ranks(v, device):
+    td = torch.tensor([v], device=_coll_device(device), dtype=torch.float64)
+    dist.all_reduce(td, op=dist.ReduceOp.MAX)
+    return float(td)
+
+
+def _from_rank0(v, device):
+    tt = torch.tensor([float(v)], device=_coll_device(device), dtype=torch.float64)
+    dist.broadcast(tt, 0)
+    return float(tt)
+
+
 def build_models(device):
     from trebi_amd import spec, synth
     from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
@@ -90,9 +108,9 @@ def other_configs(device, steps=3, world=1, rank=0, rehearse=False):
         x_T = torch.randn(nb, H, D, device=device, generator=torch.Generator(device).manual_seed(2))
         x_T[:, 0, act:] = o
         tt = cguide(x_T, None, torch.full((nb,), T - 1, device=device, dtype=torch.long)).median().reshape(1)
-        if world > 1:
-            dist.broadcast(tt, 0)
         thr = float(tt)
+        if world > 1:
+            thr = _from_rank0(thr, device)
         planner = ShardedPlanner(diff)
         run = lambda: planner.plan(o, n_global, H, fn, cost_threshold=thr, guide=guide, cost_guide=cguide, copy=False, **kw)
 
@@ -108,9 +126,7 @@ def other_configs(device, steps=3, world=1, rank=0, rehearse=False):
         fence()
         dt = (time.perf_counter() - t0) / steps
         if world > 1:
-            td = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(td, op=dist.ReduceOp.MAX)
-            dt = float(td)
+            dt = _max_over_ranks(dt, device)
         fl = T * (unet.flops() + 2 * kw['n_guide_steps'] * (guide._net().flops() + guide._net().flops(backward=True)))
         tf = fl * n_global / dt / 1e12
         entry = {'workload': f'{name}: {n_global} candidates over {world} GPU(s), {B} on this rank',
@@ -128,9 +144,7 @@ def other_configs(device, steps=3, world=1, rank=0, rehearse=False):
         fence()
         dt = (time.perf_counter() - t0) / steps
         if world > 1:
-            td = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(td, op=dist.ReduceOp.MAX)
-            dt = float(td)
+            dt = _max_over_ranks(dt, device)
         tf = fl * n_global / dt / 1e12
         entry['bf16x3'] = {'trajectories_per_s': n_global / dt, 'ms_per_step': 1e3 * dt, 'achieved': tf,
                            'peak': PEAK_BF16_MFMA_TFLOPS * world, 'unit': 'TFLOP/s (algorithmic)',
@@ -216,9 +230,7 @@ def train_step_extra(device, world, rank, batch=4096, accum=2, steps=4, cpu=True
     fence()
     dt = (time.perf_counter() - t0) / steps
     if world > 1:
-        td = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(td, op=dist.ReduceOp.MAX)
-        dt = float(td)
+        dt = _max_over_ranks(dt, device)
     fl = (tr.engine.flops() + tr.engine.flops(backward=True)) * batch * accum
     out = {'workload': f'configs[4]: halfcheetah diffusion training step, global micro-batch {batch} x {accum} accumulations per '
                        f'optimiser step, data-parallel x{world} ({Bl} samples per rank and micro-batch)',
@@ -236,9 +248,7 @@ def train_step_extra(device, world, rank, batch=4096, accum=2, steps=4, cpu=True
     fence()
     dtb = (time.perf_counter() - t0) / steps
     if world > 1:
-        td = torch.tensor([dtb], device=device, dtype=torch.float64)
-        dist.all_reduce(td, op=dist.ReduceOp.MAX)
-        dtb = float(td)
+        dtb = _max_over_ranks(dtb, device)
     out['bf16x3'] = {'samples_per_s': batch * accum / dtb, 'ms_per_optimiser_step': 1e3 * dtb, 'achieved': fl / dtb / 1e12,
                      'unit': 'TFLOP/s (algorithmic)', 'frac_of_f32_matrix_peak': fl / dtb / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
                      'note': 'forward and input-gradient convolutions on bf16x3 operands; weight gradients, loss, Adam, EMA fp32'}
@@ -418,9 +428,7 @@ def main():
     c19 = cguide(x_T, None, torch.full((B,), T - 1, device=device, dtype=torch.long))
     thr = float(c19.median())
     if world > 1:
-        tt = torch.tensor([thr], device=device)
-        dist.broadcast(tt, 0)
-        thr = float(tt)
+        thr = _from_rank0(thr, device)
     kw = dict(PLAN_KW, guide=guide, cost_guide=cguide, skip_dead_evals=args.skip_dead_evals)
 
     def step():
@@ -441,9 +449,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        td = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(td, op=dist.ReduceOp.MAX)
-        dt = float(td)
+        dt = _max_over_ranks(dt, device)
     assert torch.isfinite(plan.best_trajectory).all()
 
     # ---- roofline of the dominant kernel (the implicit-GEMM conv), measured live with HIP events on

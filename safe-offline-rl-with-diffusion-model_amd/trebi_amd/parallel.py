@@ -98,7 +98,16 @@ class ShardedPlanner:
                 # Needed with gloo, whose device-tensor path stages through the host; RCCL enqueues its kernel on a
                 # stream that waits for the current stream through an event (fence 'stream': nothing to do here).
                 torch.cuda.current_stream(send.device).synchronize()
-            dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+            if send.is_cuda and dist.get_backend(self.group) == 'gloo':
+                # gloo moves device tensors through its own staging copies; with two processes on one device (the one-GPU
+                # rehearsal of bench --gpus N) that path stalled intermittently.  The scores are 2 x m floats: exchange
+                # them from the host instead.  RCCL (backend 'nccl', one process per GPU) takes the device buffers.
+                send_h = send.cpu()
+                recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+                dist.all_gather_into_tensor(recv_h.view(-1), send_h.view(-1), group=self.group)
+                recv.copy_(recv_h)
+            else:
+                dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
             if min(sizes) == m:
                 v_all, c_all = recv[:, 0, :].reshape(-1), recv[:, 1, :].reshape(-1)
             else:
@@ -118,5 +127,10 @@ class ShardedPlanner:
         traj = x[best - lo].clone() if rank == owner else torch.empty(horizon, D, dtype=x.dtype, device=x.device)
         if world > 1:
             src = dist.get_global_rank(self.group, owner) if self.group is not None else owner
-            dist.broadcast(traj, src=src, group=self.group)
+            if traj.is_cuda and dist.get_backend(self.group) == 'gloo':      # as above: host tensors under gloo
+                traj_h = traj.cpu()
+                dist.broadcast(traj_h, src=src, group=self.group)
+                traj.copy_(traj_h)
+            else:
+                dist.broadcast(traj, src=src, group=self.group)
         return Plan(best, traj, v_all, c_all, order, x.clone() if copy else x, (lo, hi))

@@ -227,7 +227,13 @@ class Trainer:
             scale = (B / Bg if Bg else 0.0) / len(batches)                              # training.py:115
             losses.append(self.engine.accumulate(x, cond, t, noise, grad_scale=scale))
         if world > 1:
-            dist.all_reduce(self.engine.grads, op=dist.ReduceOp.SUM, group=self.group)  # the one collective per step
+            g = self.engine.grads                                                       # the one collective per step
+            if g.is_cuda and dist.get_backend(self.group) == 'gloo':      # gloo (CPU rehearsals): through the host
+                gh = g.cpu()
+                dist.all_reduce(gh, op=dist.ReduceOp.SUM, group=self.group)
+                g.copy_(gh)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
         self.adam_steps += 1
         ema_mode = 0
         if self.step % self.update_ema_every == 0:                                      # training.py:121-122, 94-98
