@@ -1028,7 +1028,13 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
           const size_t lds = conv_lds_bytes(q, t);
           if (lds > 160 * 1024) continue;
           const long wgs = (long)((B + S - 1) / S) * (units / tu) * nz;
-          const int occ = (occ_on && B >= occ_min_b) ? std::max(1, std::min(8 / (NG * KS), (int)(160 * 1024 / std::max<size_t>(lds, 1)))) : 1;
+          // waves a CU holds: 2 per SIMD for the ~200-VGPR instantiations, 3 for the ones under 168 VGPRs
+          // (hipcc -Rpass-analysis=kernel-resource-usage: (MI, NI) = (4,1), (1,2), (2,2) at 159-164)
+          // (measured: +1-2 % at 8192 candidates, -1-2 % at 512-2048, where the launches do not fill the slots anyway)
+          static const int occ3_min_b = getenv("TREBI_OCC3_MINB") ? atoi(getenv("TREBI_OCC3_MINB")) : 4096;
+          const bool small_regs = B >= occ3_min_b && ((MI == 4 && NI == 1) || (MI <= 2 && NI == 2));
+          const int cu_waves = small_regs ? 12 : 8;
+          const int occ = (occ_on && B >= occ_min_b) ? std::max(1, std::min(cu_waves / (NG * KS), (int)(160 * 1024 / std::max<size_t>(lds, 1)))) : 1;
           const long rounds = (wgs + 256 * occ - 1) / (256 * occ);
           const int chunk = (KK + KS - 1) / KS;
           // position-major tiles issue each tile's 4 MFMAs back to back behind a branch: with one column tile per
