@@ -1,0 +1,71 @@
+// Diagnostic microbenchmark: what v_mfma_f32_16x16x4_f32 sustains on gfx950 with 1 / 2 waves per SIMD, bare and with the
+// operand patterns of conv_gemm_kernel's K loop.  Not part of the product.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define GL __attribute__((address_space(1)))
+// 0: bare; 1: A from LDS per step (read, wait, multiply); 2: A one step ahead; 3: as 1 + weights streamed from global in
+// half blocks of 4 steps (8 float4 per lane per half block, consumed one block later), like the large-batch loop
+template <int MODE>
+__global__ __launch_bounds__(512) void k(float* out, const float* wts, int iters) {
+  __shared__ __attribute__((aligned(16))) float lds[16 * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 16 * 1024; i += blockDim.x) lds[i] = 1.0f + i * 1e-6f;
+  __syncthreads();
+  f32x4 acc[4][2];
+  for (int a = 0; a < 4; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 w[8][2];
+  for (int u = 0; u < 8; ++u) for (int n = 0; n < 2; ++n) w[u][n] = (f32x4){1.f, 2.f, 3.f, 4.f} * (float)(lane + u + n);
+  const f32x4* base = (const f32x4*)lds + lane;
+  const GL f32x4* wp = (const GL f32x4*)wts + wave * 32 + lane;      // 256 columns x float4 per step
+  f32x4 a[4], an[4];
+  for (int m = 0; m < 4; ++m) { a[m] = (f32x4){1.f, 1.f, 1.f, 1.f} * (float)m; an[m] = a[m]; }
+  if (MODE == 2) for (int m = 0; m < 4; ++m) an[m] = base[m * 64];
+  for (int it = 0; it < iters; it += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int off = (((it + u) & 15) * 256);
+      if (MODE == 1 || MODE == 3) { for (int m = 0; m < 4; ++m) a[m] = base[off + m * 64]; }
+      if (MODE == 2) { for (int m = 0; m < 4; ++m) a[m] = an[m]; for (int m = 0; m < 4; ++m) an[m] = base[off + m * 64]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][j], w[u][n][j], acc[m][n], 0, 0, 0);
+      if (MODE == 3 && (u & 3) == 3) {
+        const int h = u >> 2;
+        const int step = (it + 8 + 4 * h) % 320;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) w[4 * h + q][n] = wp[(size_t)(step + q) * 1024 + n * 16];
+      }
+    }
+  }
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < 4; ++m) for (int n = 0; n < 2; ++n) s += acc[m][n];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+template <int MODE>
+void run(const char* name, int threads, float* d, const float* w) {
+  const int iters = 4000, grid = 256;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(threads), 0, 0, d, w, 96);
+  (void)hipEventRecord(e0);
+  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(threads), 0, 0, d, w, iters);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  const double fl = (double)grid * (threads / 64) * iters * 32.0 * 2048.0;
+  printf("%-44s %d waves/SIMD: %7.1f TFLOP/s (%.1f %% of 157.3)\n", name, threads / 256, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+}
+int main() {
+  float *d, *w; (void)hipMalloc(&d, 256 * 512 * 4); (void)hipMalloc(&w, (size_t)330 * 1024 * 16); (void)hipMemset(w, 0, (size_t)330 * 1024 * 16);
+  run<0>("bare", 256, d, w); run<0>("bare", 512, d, w);
+  run<1>("A from LDS, read-wait-multiply", 256, d, w); run<1>("A from LDS, read-wait-multiply", 512, d, w);
+  run<2>("A from LDS, one step ahead", 256, d, w); run<2>("A from LDS, one step ahead", 512, d, w);
+  run<3>("A from LDS + weights from L2 (half blocks)", 256, d, w); run<3>("A from LDS + weights from L2 (half blocks)", 512, d, w);
+  (void)hipDeviceSynchronize();
+  return 0;
+}
