@@ -465,12 +465,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {      // two work
     }
 }
 
+__global__ void time_mlp_bwd_kernel(const float* DT, int njobs, const float* e, const float* a1, const float* temb,
+                                    const float* W3, int dim, int T, float* gW1, float* gb1, float* gW3, float* gb3);
 hipError_t train_init_device() {
   hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)time_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
 }
 
@@ -663,45 +667,60 @@ hipError_t launch_time_block_bwd(const TBJob* dev_jobs, int njobs, const float* 
   return hipGetLastError();
 }
 
-// d temb = mish'(temb) * sum_blocks DT;  then the two Linears of time_mlp backwards (one workgroup: it is tiny)
-__global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const float* DT, int njobs, const float* e, const float* a1,
-                                                           const float* temb, const float* W3, int dim, int T,
-                                                           float* gW1, float* gb1, float* gW3, float* gb3) {
+// d temb = mish'(temb) * sum_blocks DT;  then the two Linears of time_mlp backwards (one workgroup: it is tiny).
+// Everything that is read more than once sits in LDS first (Mish(a1), W3, e): the first version evaluated Mish(a1) once per
+// OUTPUT row of W3 (dim x too often) and read its operands from global memory inside the reductions: 111 us for a 20 x 32 problem.
+constexpr int TMB_THREADS = 1024;
+__global__ __launch_bounds__(TMB_THREADS) void time_mlp_bwd_kernel(const float* DT, int njobs, const float* e, const float* a1,
+                                                                   const float* temb, const float* W3, int dim, int T,
+                                                                   float* gW1, float* gb1, float* gW3, float* gb3) {
   extern __shared__ float sm[];
-  float* dte = sm;                  // [T][dim]
-  float* da1 = sm + T * dim;        // [T][4dim]
-  const int d4 = 4 * dim;
-  for (int i = threadIdx.x; i < T * dim; i += 256) {
+  const int d4 = 4 * dim, NT = TMB_THREADS;
+  float* dte = sm;                     // [T][dim]
+  float* da1 = dte + T * dim;          // [T][4dim]
+  float* ma1 = da1 + T * d4;           // [T][4dim]   Mish(a1)
+  float* ga1 = ma1 + T * d4;           // [T][4dim]   Mish'(a1)
+  float* w3s = ga1 + T * d4;           // [dim][4dim]
+  float* es = w3s + dim * d4;          // [T][dim]
+  for (int i = threadIdx.x; i < T * dim; i += NT) {
     float a = 0.f;
-    for (int j = 0; j < njobs; ++j) a += DT[(size_t)j * T * dim + i];
-    dte[i] = a * mish_grad_f(temb[i]);
+    for (int j = 0; j < njobs; ++j) a += gld(DT + (size_t)j * T * dim + i);
+    dte[i] = a * mish_grad_f(gld(temb + i));
+    es[i] = gld(e + i);
   }
+  for (int i = threadIdx.x; i < T * d4; i += NT) {
+    float m, dm;
+    mish_both(gld(a1 + i), &m, &dm);
+    ma1[i] = m;
+    ga1[i] = dm;
+  }
+  for (int i = threadIdx.x; i < dim * d4; i += NT) w3s[i] = gld(W3 + i);
   __syncthreads();
-  for (int i = threadIdx.x; i < dim * d4; i += 256) {        // gW3[j][i2] = sum_t dte[t][j] * mish(a1[t][i2])
+  for (int i = threadIdx.x; i < dim * d4; i += NT) {         // gW3[j][i2] = sum_t dte[t][j] * mish(a1[t][i2])
     const int jj = i / d4, i2 = i - jj * d4;
     float a = 0.f;
-    for (int t = 0; t < T; ++t) a = fmaf(dte[t * dim + jj], mish_f(a1[t * d4 + i2]), a);
+    for (int t = 0; t < T; ++t) a = fmaf(dte[t * dim + jj], ma1[t * d4 + i2], a);
     gW3[i] += a;
   }
-  for (int jj = threadIdx.x; jj < dim; jj += 256) {
+  for (int jj = threadIdx.x; jj < dim; jj += NT) {
     float a = 0.f;
     for (int t = 0; t < T; ++t) a += dte[t * dim + jj];
     gb3[jj] += a;
   }
-  for (int i = threadIdx.x; i < T * d4; i += 256) {          // da1[t][i2] = mish'(a1) * sum_j dte[t][j] W3[j][i2]
+  for (int i = threadIdx.x; i < T * d4; i += NT) {           // da1[t][i2] = mish'(a1) * sum_j dte[t][j] W3[j][i2]
     const int t = i / d4, i2 = i - t * d4;
     float a = 0.f;
-    for (int jj = 0; jj < dim; ++jj) a = fmaf(dte[t * dim + jj], W3[jj * d4 + i2], a);
-    da1[i] = a * mish_grad_f(a1[i]);
+    for (int jj = 0; jj < dim; ++jj) a = fmaf(dte[t * dim + jj], w3s[jj * d4 + i2], a);
+    da1[i] = a * ga1[i];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < d4 * dim; i += 256) {        // gW1[i2][k] = sum_t da1[t][i2] * e[t][k]
+  for (int i = threadIdx.x; i < d4 * dim; i += NT) {         // gW1[i2][k] = sum_t da1[t][i2] * e[t][k]
     const int i2 = i / dim, k = i - i2 * dim;
     float a = 0.f;
-    for (int t = 0; t < T; ++t) a = fmaf(da1[t * d4 + i2], e[t * dim + k], a);
+    for (int t = 0; t < T; ++t) a = fmaf(da1[t * d4 + i2], es[t * dim + k], a);
     gW1[i] += a;
   }
-  for (int i2 = threadIdx.x; i2 < d4; i2 += 256) {
+  for (int i2 = threadIdx.x; i2 < d4; i2 += NT) {
     float a = 0.f;
     for (int t = 0; t < T; ++t) a += da1[t * d4 + i2];
     gb1[i2] += a;
@@ -710,9 +729,10 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const float* DT, int 
 hipError_t launch_time_mlp_bwd(const float* DT, int njobs, const float* e, const float* a1, const float* temb,
                                const float* W3, int dim, int T, float* gW1, float* gb1, float* gW3, float* gb3,
                                hipStream_t st) {
-  const size_t lds = (size_t)T * 5 * dim * sizeof(float);
-  hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(1), dim3(256), lds, st, DT, njobs, e, a1, temb, W3, dim, T, gW1, gb1, gW3,
-                     gb3);
+  const size_t lds = ((size_t)T * (2 * dim + 12 * dim) + (size_t)dim * 4 * dim) * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(1), dim3(TMB_THREADS), lds, st, DT, njobs, e, a1, temb, W3, dim, T, gW1, gb1,
+                     gW3, gb3);
   return hipGetLastError();
 }
 
