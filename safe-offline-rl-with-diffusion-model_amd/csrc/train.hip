@@ -248,8 +248,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* src, int ld, l
   for (int cb = 0; cb < C; cb += CW) {           // (C <= 256 everywhere on this path: one trip); uniform trip count
     const int cc = cb + c;
     float a = 0.f;
-    if (cc < C)
-      for (long r = r0 + rl; r < r1; r += nrl) a += gld(src + r * ld + cc);
+    if (cc < C) {
+      // four independent loads in flight per lane (one per trip left the loop waiting a memory latency per row)
+      float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      long r = r0 + rl;
+      for (; r + 3 * nrl < r1; r += 4 * nrl) {
+        a += gld(src + r * ld + cc);
+        a1 += gld(src + (r + nrl) * ld + cc);
+        a2 += gld(src + (r + 2 * nrl) * ld + cc);
+        a3 += gld(src + (r + 3 * nrl) * ld + cc);
+      }
+      for (; r < r1; r += nrl) a += gld(src + r * ld + cc);
+      a = (a + a1) + (a2 + a3);
+    }
     red[threadIdx.x] = a;
     __syncthreads();
     if (rl == 0 && cc < C) {
