@@ -28,8 +28,12 @@ namespace trebi {
 
 #ifdef TREBI_STAMPS
 __device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_wave_stamps[8][16];
 extern "C" int trebi_debug_read_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+extern "C" int trebi_debug_read_wave_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(g_wave_stamps));
 }
 #endif
 

@@ -20,12 +20,15 @@ __device__ __forceinline__ void gst4(float* p, f32x4 v) { *(TREBI_GLOBAL f32x4*)
 
 #ifdef TREBI_STAMPS          // diagnostic build only: per-phase cycle stamps of workgroup (0,0,0), wave 0
 extern __device__ unsigned long long g_stamps[32];
+extern __device__ unsigned long long g_wave_stamps[8][16];     // the same per wave of workgroup (0,0,0)
 #define STAMP(i)                                                                                  \
   do {                                                                                            \
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {              \
       g_stamps[i] = __builtin_amdgcn_s_memtime();                                                 \
       g_stamps[16 + i] = __builtin_amdgcn_s_memrealtime();                                        \
     }                                                                                             \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0 && threadIdx.x < 512)  \
+      g_wave_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime();                          \
   } while (0)
 #else
 #define STAMP(i)

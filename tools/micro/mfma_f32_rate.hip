@@ -26,15 +26,37 @@ __global__ __launch_bounds__(512) void k(float* out, const float* wts, int iters
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int off = (((it + u) & 15) * 256);
-      if (MODE == 1 || MODE == 3) { for (int m = 0; m < 4; ++m) a[m] = base[off + m * 64]; }
+      if (MODE >= 5) {      // a step the scheduler cannot reorder across (the real loop branches per step): read, wait, multiply
+        __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < 4; ++m) a[m] = base[off + m * 64];
+      }
+      if (MODE == 1 || MODE == 3 || MODE == 4) { for (int m = 0; m < 4; ++m) a[m] = base[off + m * 64]; }
       if (MODE == 2) { for (int m = 0; m < 4; ++m) a[m] = an[m]; for (int m = 0; m < 4; ++m) an[m] = base[off + m * 64]; }
+      if (MODE == 4) {      // tile-major order of the position-major tiles: an accumulator comes back after ONE other MFMA
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][j], w[u][n][j], acc[m][n], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][j], w[u][n][j], acc[m][n], 0, 0, 0);
-      if (MODE == 3 && (u & 3) == 3) {
+      }
+      if (MODE == 6) {      // + every accumulator copied after the step (what the register allocator leaves at the joins)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("v_mov_b32 %0, %0" : "+v"(acc[m][n][e]));
+      }
+      if (MODE >= 5) __builtin_amdgcn_sched_barrier(0);
+      if ((MODE == 3 || MODE == 4 || MODE >= 5) && (u & 3) == 3) {
         const int h = u >> 2;
         const int step = (it + 8 + 4 * h) % 320;
 #pragma unroll
@@ -66,6 +88,9 @@ int main() {
   run<1>("A from LDS, read-wait-multiply", 256, d, w); run<1>("A from LDS, read-wait-multiply", 512, d, w);
   run<2>("A from LDS, one step ahead", 256, d, w); run<2>("A from LDS, one step ahead", 512, d, w);
   run<3>("A from LDS + weights from L2 (half blocks)", 256, d, w); run<3>("A from LDS + weights from L2 (half blocks)", 512, d, w);
+  run<4>("same, tile-major MFMA order (PM tiles)", 256, d, w); run<4>("same, tile-major MFMA order (PM tiles)", 512, d, w);
+  run<5>("fenced steps (read, wait, multiply) + L2 weights", 256, d, w); run<5>("fenced steps (read, wait, multiply) + L2 weights", 512, d, w);
+  run<6>("same + all accumulators copied per step", 256, d, w); run<6>("same + all accumulators copied per step", 512, d, w);
   (void)hipDeviceSynchronize();
   return 0;
 }
