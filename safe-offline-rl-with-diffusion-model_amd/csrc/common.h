@@ -118,6 +118,7 @@ size_t conv_lds_bytes(const ConvP& p, const Tile& tl);
 hipError_t conv_init_device();
 hipError_t launch_conv(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st);
 ConvGeo conv_make_geo(const ConvP& p, const Tile& tl);
+bool conv_w5_ok(const ConvP& p, const Tile& tl);     // the layer / tile pairs that take the channel-block-major K loop
 bool conv_vec_ok(const ConvP& p);
 bool chain_variant_ok(int MI, int NI);
 hipError_t chain_init_device();

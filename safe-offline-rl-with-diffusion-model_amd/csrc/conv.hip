@@ -45,6 +45,13 @@ bool conv_vec_ok(const ConvP& q) {
   return v;
 }
 
+// The layers and tiles that take the channel-block-major K loop (conv_body, W5).
+bool conv_w5_ok(const ConvP& p, const Tile& tl) {
+  static const bool w5_on = !(getenv("TREBI_WIN5") && atoi(getenv("TREBI_WIN5")) == 0);
+  return w5_on && tl.pm && !tl.bf && tl.KS == 1 && p.stride == 1 && p.ntaps == 5 && p.tap_lo == 0 && p.pad == 2 &&
+         p.Lin == p.Lout && (p.Lout == tl.MI || (tl.MI >= 4 && 2 * p.Lout == tl.MI)) && ((p.Cin_p >> 4) & 1) == 0;
+}
+
 ConvGeo conv_make_geo(const ConvP& p, const Tile& tl) {
   ConvGeo g{};
   g.S = tl.S; g.NG = tl.NG; g.KS = tl.KS; g.nthr = 64 * tl.NG * tl.KS;
@@ -158,7 +165,13 @@ struct ConvPre {
 // 32-channel step k), the staged activations are converted once on their way into LDS (a row keeps its byte size: hi
 // plane then lo plane), and the K loop issues three 16x16x32 bf16 MFMAs per 32 channels.  Layers with the fused
 // GroupNorm-backward prologue are not taken in this mode (the host keeps them on the fp32 pipe).
-template <int MI, int NI, bool VEC, bool PM, bool BF>
+// W5 (position-major fp32 tiles only, an instantiation of its own so that no other K loop shares its registers): the
+// channel-block-major reduction for 5-tap stride-1 "same" convolutions whose L positions are the wave's MI tiles.  Tile mi
+// is output position mi of 16 candidates and input position q sits (q - mi) taps away, so per 16-channel block the MI
+// input positions are read from LDS ONCE and feed every (tile, tap) pair that exists -- 14 MFMA groups from 4 reads at
+// L = 4, where the tap-major loop reads one operand per pair.  The operand reads are what the large-batch K loop pays
+// for: no branch inside a block, accumulators in place, the next block's five weight rows in flight.
+template <int MI, int NI, bool VEC, bool PM, bool BF, bool W5 = false>
 __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float* smem, const int by, const int n0,
                                           const int tid) {
   constexpr int WB = (NI == 1) ? (MI <= 2 ? 24 : 16) : 8;
@@ -183,7 +196,8 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
   // (vmcnt(0)) in front of the weight loads
   const unsigned wlane = (__umul24((unsigned)g, (unsigned)Npad) + (unsigned)(n0 + ng * NI * 16 + lr)) * 4u;
   const unsigned wstep = (unsigned)Npad * 16u;     // floats per kk step
-  f32x4 wreg[WB][NI];
+  constexpr int WT = 5;                                  // taps of the W5 loop
+  f32x4 wreg[W5 ? 2 * WT : WB][NI];                      // W5: two groups of WT weight rows
   // A reduction longer than one register block (large batches: no split-K) is software-pipelined in half
   // blocks: while one half's MFMAs run, the other half's registers are refilled for the next block.  Those
   // loads are unconditional -- steps past the layer re-read its last step -- so that the compiler's vmcnt
@@ -209,7 +223,24 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
       for (int ni = 0; ni < NI; ++ni) wreg[u0 + u][ni] = gld4(wu + wlane + ni * 64);
     }
   };
-  if (multi) {
+  // W5: weight GROUP G < cb5 = the five taps of channel block G; G >= cb5 = five consecutive steps of the second source
+  // (clamped to the last step: the loads stay unconditional, so the vmcnt waits are exact counts).
+  const int cb5 = (int)((unsigned)KK1 / 5u);
+  auto wgroup = [&](auto slot_tag, int G) {
+    constexpr int slot = decltype(slot_tag)::value;
+#pragma unroll
+    for (int u = 0; u < WT; ++u) {
+      int k2 = KK1 + WT * (G - cb5) + u;
+      k2 = k2 < k_last ? k2 : k_last;
+      const int k = G < cb5 ? u * cb5 + G : k2;
+      const float* wu = pw + (unsigned)k * wstep;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wreg[slot * WT + u][ni] = gld4(wu + wlane + ni * 64);
+    }
+  };
+  if constexpr (W5) {
+    wgroup(std::integral_constant<int, 0>{}, 0);
+  } else if (multi) {
     wload(0, k_begin);
     wload(HB, k_begin + HB);
   } else if constexpr (STR) {
@@ -578,7 +609,72 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
       }
     }
   };
-  if constexpr (BF) {
+  if constexpr (W5) {
+    const int K2 = KK - KK1, n2g = (K2 + WT - 1) / WT;
+    int fb[MI];
+#pragma unroll
+    for (int q = 0; q < MI; ++q) fb[q] = rowA[q] + 2 * ldA;          // rowA[q] is tap 0 of tile q: input position q - 2
+    // NB candidate blocks of L = MI / NB positions each: tile mi = position mi % L of block mi / L
+    auto first = [&](auto slot_tag, auto nb_tag, int G) {
+      constexpr int slot = decltype(slot_tag)::value;
+      constexpr int LL = MI / decltype(nb_tag)::value;
+      f32x4 f[MI];
+#pragma unroll
+      for (int q = 0; q < MI; ++q) f[q] = *(const f32x4*)&slab[fb[q] + G * 16];
+      wgroup(std::integral_constant<int, slot ^ 1>{}, G + 1);
+      __builtin_amdgcn_sched_barrier(0x386);   // only the requests may not cross: they stay in front of this block's MFMAs
+#pragma unroll
+      for (int tau = 0; tau < WT; ++tau)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int q = mi % LL + tau - 2;                          // input position within the tile's block
+            if (q >= 0 && q < LL) {
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[q >= 0 && q < LL ? mi - mi % LL + q : 0][j],
+                                                                   wreg[slot * WT + tau][ni][j], acc[mi][ni], 0, 0, 0);
+            }
+          }
+    };
+    auto second = [&](auto slot_tag, int Gs) {
+      constexpr int slot = decltype(slot_tag)::value;
+      wgroup(std::integral_constant<int, slot ^ 1>{}, cb5 + Gs + 1);
+      __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+      for (int u = 0; u < WT; ++u) {
+        const int k2 = WT * Gs + u;
+        if (k2 < K2) {
+          f32x4 a[MI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)&slab2[row2[mi] + k2 * 16];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc2[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], wreg[slot * WT + u][ni][j], acc2[mi][ni], 0, 0, 0);
+        }
+      }
+    };
+    if (Lout == MI) {
+      for (int G = 0; G < cb5; G += 2) {                             // cb5 is even (launch_conv_t)
+        first(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, G);
+        first(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, G + 1);
+      }
+    } else if constexpr (MI >= 4) {                                  // two candidate blocks per row tile set
+      for (int G = 0; G < cb5; G += 2) {
+        first(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, G);
+        first(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, G + 1);
+      }
+    }
+    for (int Gs = 0; Gs < n2g; Gs += 2) {
+      second(std::integral_constant<int, 0>{}, Gs);
+      if (Gs + 1 < n2g) second(std::integral_constant<int, 1>{}, Gs + 1);
+    }
+  } else if constexpr (BF) {
     if (multi) {
       for (int base = k_begin; base < k_end; base += WB) {
         int tau = dCb.div(base), cb = base - tau * cbpt;
@@ -848,7 +944,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
 }
 
 constexpr int CPRE_DW = 12;          // dwords of kernel arguments in front of the descriptor (11 used + alignment)
-template <int MI, int NI, bool VEC, bool PM, bool BF>
+template <int MI, int NI, bool VEC, bool PM, bool BF, bool W5 = false>
 __global__ __launch_bounds__(512) void conv_gemm_kernel(const float* w0, const float* w1, int Npad, int TN, int NG,
                                                         unsigned mNG, int chunk, int KK, int KK1, ConvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -866,7 +962,7 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const float* w0, const f
   // blockIdx.x = column tile, blockIdx.y = candidate group: workgroups are dealt to the 8 XCDs round-robin by
   // linear id, so the workgroups that share a weight slice land on the same XCD (one L2 fetches the slice
   // instead of all eight; the activations are tiny)
-  conv_body<MI, NI, VEC, PM, BF>(dv, pre, smem, blockIdx.y, blockIdx.x * TN, threadIdx.x);
+  conv_body<MI, NI, VEC, PM, BF, W5>(dv, pre, smem, blockIdx.y, blockIdx.x * TN, threadIdx.x);
 }
 
 template <int MI, int NI, bool PM>
@@ -887,9 +983,20 @@ static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hip
     if (!vec || p.pro || (p.Cin_p & 31) || (p.x2 && (p.Cin2_p & 31)) || (g.chunk & 1) || (g.KK & 1)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM, true>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
                        g.chunk, g.KK, g.KK1, LL);
-  } else if (vec)
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM, false>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
-                       g.chunk, g.KK, g.KK1, LL);
+  } else if (vec) {
+    // the channel-block-major loop (conv_body, W5): 5-tap stride-1 "same" convolution whose positions are the wave's MI tiles,
+    // the whole reduction in every wave, an even number of channel blocks
+    bool w5 = false;
+    if constexpr (PM)
+      w5 = conv_w5_ok(p, tl) && g.fhk == 2 && g.nv == p.Lout && g.KK1 == 5 * g.cbpt;
+    if (w5) {
+      if constexpr (PM)
+        hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM, false, true>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG,
+                           g.mNG, g.chunk, g.KK, g.KK1, LL);
+    } else
+      hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM, false>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
+                         g.chunk, g.KK, g.KK1, LL);
+  }
   else
     hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, false, PM, false>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG, g.mNG,
                        g.chunk, g.KK, g.KK1, LL);
@@ -915,6 +1022,12 @@ hipError_t conv_init_device() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   TREBI_TILES(TREBI_ATTR)
 #undef TREBI_ATTR
+#define TREBI_ATTR5(mi, ni)                                                                    \
+  if (e == hipSuccess)                                                                       \
+    e = hipFuncSetAttribute((const void*)conv_gemm_kernel<mi, ni, true, true, false, true>,  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  TREBI_ATTR5(2, 1) TREBI_ATTR5(4, 1) TREBI_ATTR5(8, 1) TREBI_ATTR5(2, 2) TREBI_ATTR5(4, 2)
+#undef TREBI_ATTR5
   return e;
 }
 

@@ -959,7 +959,7 @@ int gcd(int a, int b) { return b ? gcd(b, a % b) : a; }
 // VGPRs, so one 512-thread workgroup is resident per compute unit: a launch takes ceil(workgroups / 256)
 // rounds of one workgroup lifetime each.  Enumerate the shapes the kernel is instantiated for and take the
 // cheapest by a small cost model (fixed per-workgroup latency + matrix-core time per SIMD + staging).
-Tile choose_tile(const Op& op, int B, int nz = 1) {
+Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
   int Lout = op.Lout;
   if (Lout > 128) unsupported("sequence length %d > 128 is not tiled", Lout);
   auto mi_for = [&](int s) {
@@ -1039,7 +1039,13 @@ Tile choose_tile(const Op& op, int B, int nz = 1) {
           const int chunk = (KK + KS - 1) / KS;
           // position-major tiles issue each tile's 4 MFMAs back to back behind a branch: with one column tile per
           // wave (NI == 1) they form a dependent chain (40 instead of 32 cycles each) -- measured, not modelled finer
-          const double pmk = pm ? (NI == 1 ? 1.25 : 1.05) : 1.0;
+          // (the channel-block-major loop of conv_w5_ok has neither the chain nor the branches; what it pays for is its
+          // weight stream, so the eight-tile one-column waves, with half the requests per MFMA, come out ~10 % ahead of
+          // the four-tile ones, which run as fast as the tap-major loop did: measured per layer at 8192 candidates)
+          t.bf = bf;
+          const bool w5 = pm && conv_w5_ok(q, t);
+          t.bf = 0;                                    // the caller sets it once the operands are known to qualify
+          const double pmk = pm ? (NI == 1 ? (w5 ? (MI == 8 ? 0.92 : 1.05) : 1.25) : 1.05) : 1.0;
           const double mfma = 32.0 * 4 * MI * NI * chunk * frac * pmk;     // cycles of one wave's matrix work
           const double simd = mfma * std::max(1.0, occ * NG * KS / 4.0);   // waves of a SIMD share its matrix core
           const double nthr = 64.0 * NG * KS;
@@ -1154,8 +1160,9 @@ int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, 
     L.p[0] = r0.conv(op);
     if (n1) L.p[1] = r1.conv((*ops1)[i]);
     Tile tl;
+    const bool bf = use_bf(n0, op, B) && conv_vec_ok(L.p[0]) && (!n1 || (use_bf(n1, (*ops1)[i], B) && conv_vec_ok(L.p[1])));
     try {
-      tl = choose_tile(op, B, nz);
+      tl = choose_tile(op, B, nz, bf);
     } catch (const Unsupported& u) {
       return fail(TREBI_UNSUPPORTED_CONFIG, "%s", u.msg.c_str());
     }
@@ -1163,7 +1170,7 @@ int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, 
     if (tl.S * op.Lout > 16 * tl.MI || op.Npad % (16 * tl.NI * tl.NG) || 64 * tl.NG * tl.KS > 512 ||
         (op.pro && (op.stride != 1 || op.Lin != op.Lout)) || !L.p[0].x || !L.p[0].out)
       return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
-    if (use_bf(n0, op, B) && conv_vec_ok(L.p[0]) && (!n1 || (use_bf(n1, (*ops1)[i], B) && conv_vec_ok(L.p[1])))) {
+    if (bf) {
       tl.bf = 1;
       L.p[0].w = op.w16;
       if (n1) L.p[1].w = (*ops1)[i].w16;
@@ -1521,8 +1528,9 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
     st.kind = 0; st.nz = nz;
     st.L.p[0] = r0.conv(op);
     if (r1) st.L.p[1] = r1->conv(*o1[i]);
+    const bool bf = use_bf(r0.net, op, B) && conv_vec_ok(st.L.p[0]) && (!r1 || (use_bf(r1->net, *o1[i], B) && conv_vec_ok(st.L.p[1])));
     try {
-      st.tl = choose_tile(op, B, nz);
+      st.tl = choose_tile(op, B, nz, bf);
     } catch (const Unsupported& u) {
       return fail(TREBI_UNSUPPORTED_CONFIG, "%s", u.msg.c_str());
     }
@@ -1530,7 +1538,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
         (op.pro && (op.stride != 1 || op.Lin != op.Lout)) || !st.L.p[0].x || !st.L.p[0].out)
       return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
     st.flops = op.flops * B * nz;
-    if (use_bf(r0.net, op, B) && conv_vec_ok(st.L.p[0]) && (!r1 || (use_bf(r1->net, *o1[i], B) && conv_vec_ok(st.L.p[1])))) {
+    if (bf) {
       st.tl.bf = 1;
       st.L.p[0].w = op.w16;
       if (r1) st.L.p[1].w = o1[i]->w16;

@@ -2,21 +2,28 @@
 // operand patterns of conv_gemm_kernel's K loop.  Not part of the product.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GL __attribute__((address_space(1)))
 // 0: bare; 1: A from LDS per step (read, wait, multiply); 2: A one step ahead; 3: as 1 + weights streamed from global in
 // half blocks of 4 steps (8 float4 per lane per half block, consumed one block later), like the large-batch loop
 template <int MODE>
-__global__ __launch_bounds__(512) void k(float* out, const float* wts, int iters) {
+__global__ __launch_bounds__(512) void k(float* out, const float* wts, int iters, int rnd) {
   __shared__ __attribute__((aligned(16))) float lds[16 * 1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 16 * 1024; i += blockDim.x) lds[i] = 1.0f + i * 1e-6f;
+  // argv[2] = 1: operands with random mantissas (the power drawn by the matrix pipe depends on the data: zeros and
+  // near-constants toggle few bits)
+  for (int i = threadIdx.x; i < 16 * 1024; i += blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    lds[i] = rnd ? (float)(int)(h & 0xffffff) * (1.0f / 8388608.0f) - 1.0f : 1.0f + i * 1e-6f;
+  }
   __syncthreads();
   f32x4 acc[4][2];
   for (int a = 0; a < 4; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 w[8][2];
-  for (int u = 0; u < 8; ++u) for (int n = 0; n < 2; ++n) w[u][n] = (f32x4){1.f, 2.f, 3.f, 4.f} * (float)(lane + u + n);
+  for (int u = 0; u < 8; ++u) for (int n = 0; n < 2; ++n) w[u][n] = (f32x4){1.f, 2.f, 3.f, 4.f} * (float)(lane + u + n) * (rnd ? 1.37e-3f : 1.f);
   const f32x4* base = (const f32x4*)lds + lane;
   const GL f32x4* wp = (const GL f32x4*)wts + wave * 32 + lane;      // 256 columns x float4 per step
   f32x4 a[4], an[4];
@@ -70,20 +77,31 @@ __global__ __launch_bounds__(512) void k(float* out, const float* wts, int iters
   for (int m = 0; m < 4; ++m) for (int n = 0; n < 2; ++n) s += acc[m][n];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
+static int g_rnd = 0;
+static int g_iters = 4000;        // argv[1]: longer runs show the SUSTAINED rate (clocks under power management)
 template <int MODE>
 void run(const char* name, int threads, float* d, const float* w) {
-  const int iters = 4000, grid = 256;
+  const int iters = g_iters, grid = 256;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(threads), 0, 0, d, w, 96);
+  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(threads), 0, 0, d, w, 96, g_rnd);
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(threads), 0, 0, d, w, iters);
+  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(threads), 0, 0, d, w, iters, g_rnd);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   const double fl = (double)grid * (threads / 64) * iters * 32.0 * 2048.0;
-  printf("%-44s %d waves/SIMD: %7.1f TFLOP/s (%.1f %% of 157.3)\n", name, threads / 256, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+  printf("%-44s %d waves/SIMD: %7.1f TFLOP/s (%.1f %% of 157.3) in %.1f ms\n", name, threads / 256, fl / ms / 1e9,
+         fl / ms / 1e9 / 157.3 * 100, ms);
 }
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_iters = atoi(argv[1]) & ~7;
+  if (argc > 2) g_rnd = atoi(argv[2]);
   float *d, *w; (void)hipMalloc(&d, 256 * 512 * 4); (void)hipMalloc(&w, (size_t)330 * 1024 * 16); (void)hipMemset(w, 0, (size_t)330 * 1024 * 16);
+  if (g_rnd) {
+    std::vector<float> hw((size_t)330 * 1024 * 4);
+    unsigned h = 12345u;
+    for (auto& v : hw) { h = h * 1664525u + 1013904223u; v = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f; }
+    (void)hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+  }
   run<0>("bare", 256, d, w); run<0>("bare", 512, d, w);
   run<1>("A from LDS, read-wait-multiply", 256, d, w); run<1>("A from LDS, read-wait-multiply", 512, d, w);
   run<2>("A from LDS, one step ahead", 256, d, w); run<2>("A from LDS, one step ahead", 512, d, w);
