@@ -48,7 +48,9 @@ bool conv_vec_ok(const ConvP& q) {
 // The layers and tiles that take the channel-block-major K loop (conv_body, W5).
 bool conv_w5_ok(const ConvP& p, const Tile& tl) {
   static const bool w5_on = !(getenv("TREBI_WIN5") && atoi(getenv("TREBI_WIN5")) == 0);
-  return w5_on && tl.pm && !tl.bf && tl.KS == 1 && p.stride == 1 && p.ntaps == 5 && p.tap_lo == 0 && p.pad == 2 &&
+  // from 4096 candidates up: measured +3 % there and at 8192, -1 % at 1024, -3 % at 2048 (value net and UNet passes alone)
+  static const int w5_min_b = getenv("TREBI_WIN5_MINB") ? atoi(getenv("TREBI_WIN5_MINB")) : 4096;
+  return w5_on && p.B >= w5_min_b && tl.pm && !tl.bf && tl.KS == 1 && p.stride == 1 && p.ntaps == 5 && p.tap_lo == 0 && p.pad == 2 &&
          p.Lin == p.Lout && (p.Lout == tl.MI || (tl.MI >= 4 && 2 * p.Lout == tl.MI)) && ((p.Cin_p >> 4) & 1) == 0;
 }
 

@@ -982,7 +982,7 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
   q.Cin2_p = op.Cin2_p; q.gn = op.gn; q.gch = op.gn ? op.gnw.gch : 1;
   q.Lin = op.Lin; q.pro = op.pro ? 1 : 0; q.tbias = op.tbias;
   q.res = op.res.id != NONE ? (const float*)1 : nullptr;
-  q.tap_lo = op.tap_lo; q.pad = op.pad;
+  q.tap_lo = op.tap_lo; q.pad = op.pad; q.B = B;
   const int R = (op.Lout - 1) * op.stride + op.ntaps;
   Tile best{};
   double best_cost = -1;
