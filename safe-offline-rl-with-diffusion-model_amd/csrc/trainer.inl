@@ -506,21 +506,23 @@ extern "C" int trebi_trainer_accumulate(trebi_trainer* tr, const float* x_start,
     sp.cond[k] = cond[k];
   }
   // ---- tiles of every conv launch for this batch size (resolved once) ----
-  auto itf = tr->tiles_fwd.find(B);
+  // (per batch size AND operand mode: the chooser prices the fp32-only K loops differently)
+  const int tkey = B | (net->prec == 1 ? 1 << 30 : 0);
+  auto itf = tr->tiles_fwd.find(tkey);
   if (itf == tr->tiles_fwd.end()) {
     std::vector<Tile> tf(net->fwd.size()), tb(net->tops.size());
     try {
-      for (size_t i = 0; i < net->fwd.size(); ++i) tf[i] = choose_tile(net->fwd[i], B, 1);
+      for (size_t i = 0; i < net->fwd.size(); ++i) tf[i] = choose_tile(net->fwd[i], B, 1, use_bf(net, net->fwd[i], B));
       for (size_t i = 0; i < net->tops.size(); ++i)
-        if (net->tops[i].kind == 0) tb[i] = choose_tile(net->tops[i].conv, B, 1);
+        if (net->tops[i].kind == 0) tb[i] = choose_tile(net->tops[i].conv, B, 1, use_bf(net, net->tops[i].conv, B));
     } catch (const Unsupported& u) {
       return fail(TREBI_UNSUPPORTED_CONFIG, "%s", u.msg.c_str());
     }
-    tr->tiles_bwd[B] = tb;
-    itf = tr->tiles_fwd.emplace(B, tf).first;
+    tr->tiles_bwd[tkey] = tb;
+    itf = tr->tiles_fwd.emplace(tkey, tf).first;
   }
   const std::vector<Tile>& tf = itf->second;
-  const std::vector<Tile>& tbw = tr->tiles_bwd[B];
+  const std::vector<Tile>& tbw = tr->tiles_bwd[tkey];
 
   // ---- q_sample + conditioning, forward, loss (diffusion.py:240-254) ----
   HIPCHK(launch_qsample(sp, x_start, noise, (const long long*)tsteps, tr->sa, tr->sb, tr->xnoisy, B, st));

@@ -1032,7 +1032,8 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
           // (hipcc -Rpass-analysis=kernel-resource-usage: (MI, NI) = (4,1), (1,2), (2,2) at 159-164)
           // (measured: +1-2 % at 8192 candidates, -1-2 % at 512-2048, where the launches do not fill the slots anyway)
           static const int occ3_min_b = getenv("TREBI_OCC3_MINB") ? atoi(getenv("TREBI_OCC3_MINB")) : 4096;
-          const bool small_regs = B >= occ3_min_b && ((MI == 4 && NI == 1) || (MI <= 2 && NI == 2));
+          // (the bf16x3 instantiations of the same shapes need 170-175: two waves per SIMD)
+          const bool small_regs = !bf && B >= occ3_min_b && ((MI == 4 && NI == 1) || (MI <= 2 && NI == 2));
           const int cu_waves = small_regs ? 12 : 8;
           const int occ = (occ_on && B >= occ_min_b) ? std::max(1, std::min(cu_waves / (NG * KS), (int)(160 * 1024 / std::max<size_t>(lds, 1)))) : 1;
           const long rounds = (wgs + 256 * occ - 1) / (256 * occ);
@@ -1053,7 +1054,12 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
                                        (double)S * Lout * op.Cin2_p / 4) / nthr;
           const double epi = 60.0 * (16.0 * MI * 16 * tu / 4) / nthr;
           const double wload = 8.0 * chunk * NI;                           // issue + latency share of the weight stream
-          const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload + (resg ? 2500.0 : 0.0));
+          // the three-waves-per-SIMD instantiations come out 15-25 % ahead of what the terms above say on the narrow layers
+          // (<= 64 output columns; per-layer times of the model's first four choices at 8192 candidates, tools/layer_profile.py
+          // + TREBI_TILE_RANK; configs[3] 392.5 -> 384.3 ms, flat for a factor between 0.6 and 0.9; on the wide layers and
+          // at 4096 candidates the same factor loses)
+          static const double k3 = getenv("TREBI_OCC3_GAIN") ? atof(getenv("TREBI_OCC3_GAIN")) : 0.8;
+          const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload + (resg ? 2500.0 : 0.0)) * (small_regs && op.Npad <= 64 && B >= 8192 ? k3 : 1.0);
           if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; }
           ranked.push_back({cost, t});
         }
