@@ -1058,8 +1058,10 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
           // (<= 64 output columns; per-layer times of the model's first four choices at 8192 candidates, tools/layer_profile.py
           // + TREBI_TILE_RANK; configs[3] 392.5 -> 384.3 ms, flat for a factor between 0.6 and 0.9; on the wide layers and
           // at 4096 candidates the same factor loses)
+          static const double resg_cost = getenv("TREBI_RESG_COST") ? atof(getenv("TREBI_RESG_COST")) : 500.0;
+          static const bool k3_all = getenv("TREBI_OCC3_ALL") && atoi(getenv("TREBI_OCC3_ALL")) == 1;
           static const double k3 = getenv("TREBI_OCC3_GAIN") ? atof(getenv("TREBI_OCC3_GAIN")) : 0.8;
-          const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload + (resg ? 2500.0 : 0.0)) * (small_regs && op.Npad <= 64 && B >= 8192 ? k3 : 1.0);
+          const double cost = rounds * (11000.0 + 1.4 * simd + stage + epi + wload + (resg ? resg_cost : 0.0)) * (small_regs && op.Npad <= 64 && B >= 8192 && (k3_all || units == tu) ? k3 : 1.0);
           if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; }
           ranked.push_back({cost, t});
         }
