@@ -30,3 +30,15 @@ def test_golden_loops_under_path(name):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+def test_full_size_copies_with_the_tap_major_loop():
+    """From 4096 candidates up the position-major tiles of the 5-tap layers run the channel-block-major K loop (conv_body W5,
+    DESIGN section 4 (v)); `test_gpu_fullsize.py` covers it at 8192 candidates under the default policy.  Here the same
+    full-size check runs with that loop switched off, so the tap-major loop it replaced stays pinned to the golden chains too."""
+    env = dict(os.environ, TREBI_WIN5='0')
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_gpu_fullsize.py'), '-q', '-x', '-m', 'gpu',
+           '-k', 'walker148', '-p', 'no:cacheprovider', '--timeout', '200', '--timeout-method', 'thread']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
