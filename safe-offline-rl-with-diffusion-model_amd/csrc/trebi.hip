@@ -1011,7 +1011,10 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
           t.resg = resg;
           double frac = 1.0;                          // share of (position, tap) pairs that touch real input rows
           int rows = R;
+          static const char* dbg = getenv("TREBI_CHOOSER_DEBUG");          // diagnostics: layer-name substring
+          const bool say = dbg && op.name.find(dbg) != std::string::npos;
           if (pm) {
+            if (say) fprintf(stderr, "[chooser %s B=%d] pm candidate S=%d MI=%d NI=%d NG=%d KS=%d resg=%d Lout=%d\n", op.name.c_str(), B, S, MI, NI, NG, KS, resg, Lout);
             if (!pm_on || B < pm_min_b || S % 16 || S * Lout != 16 * MI) continue;
             const ConvGeo g0 = conv_make_geo(q, Tile{MI, NI, NG, KS, S});
             if (g0.hr == 0) continue;                 // no zero padding to skip
@@ -1026,6 +1029,7 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
             rows = g0.nv;
           }
           const size_t lds = conv_lds_bytes(q, t);
+          if (say) fprintf(stderr, "[chooser %s] S=%d MI=%d NI=%d NG=%d KS=%d pm=%d resg=%d lds=%zu\n", op.name.c_str(), S, MI, NI, NG, KS, pm, resg, lds);
           if (lds > 160 * 1024) continue;
           const long wgs = (long)((B + S - 1) / S) * (units / tu) * nz;
           // waves a CU holds: 2 per SIMD for the ~200-VGPR instantiations, 3 for the ones under 168 VGPRs
