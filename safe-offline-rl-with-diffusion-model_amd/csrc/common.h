@@ -64,6 +64,7 @@ struct ConvGeo {
   int nv, vlo, fh, hr;                            // valid input rows [vlo, vlo+nv) per candidate, front / total halo rows
   int pm, fhk;                                    // position-major tiles (see Tile::pm): flag, front halo of the K loop
   int resg;                                       // identity residual read from global memory in the epilogue (no LDS tile)
+  int x2late;                                     // second source staged INTO the slab after the first source's reduction (W5)
   // LDS carve, float offsets:  [slab | slab2 | yslab] aliased by [red | red2] ; res | colp | tbrow | pstat
   int oSlab2, oY, red1, oRes, oColp, oTb, oPstat, total;
   int c4n, c4n2, nValid4, nHalo4, nX24, nRes4, tn4;   // float4 counts of the staged streams

@@ -97,7 +97,13 @@ ConvGeo conv_make_geo(const ConvP& p, const Tile& tl) {
   g.CS = cand_stride(g.R * g.ldA);
   g.CS2 = p.x2 ? cand_stride(p.Lout * g.ld2) : 0;
   int nA = g.S * g.CS, n2 = p.x2 ? g.S * g.CS2 : 0, nY = p.pro ? g.S * p.Lin * g.ldA : 0;
-  g.oSlab2 = nA;
+  // The channel-block-major loop (conv_w5_ok) is done with the slab before it turns to the second source, so the second
+  // source is staged into the slab's space THEN (one exposed staging pass, two barriers) instead of next to it: 16
+  // candidates of the 256-channel backward layers and 32 of the forward ones fit the 160 KB that way.
+  static const bool late_on = !(getenv("TREBI_X2LATE") && atoi(getenv("TREBI_X2LATE")) == 0);
+  g.x2late = (late_on && p.x2 && n2 <= nA && conv_w5_ok(p, tl)) ? 1 : 0;
+  g.oSlab2 = g.x2late ? 0 : nA;
+  if (g.x2late) n2 = 0;
   g.oY = nA + n2;
   g.red1 = g.KS * g.TM * g.TNp;
   int red = g.red1 * (p.x2 ? 2 : 1), stage = nA + n2 + nY;
@@ -298,6 +304,38 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
   const FastDiv dLout(Lout, CG(mLout)), dTN4(CG(tn4), CG(mTN4)), dTN(TN, CG(mTN));
   const int nvs = (B - b0 < S) ? B - b0 : S;       // candidates of this tile that exist
 
+  // second source rows at the output positions -> slab2 (with the other streams below, or -- x2late -- after the first
+  // source's reduction, into the space of the slab)
+  const bool x2late = W5 && CG(x2late) != 0;
+  auto stage_x2 = [&]() {
+    const FastDiv dC4(CG(c4n2), CG(mC4b));
+    const int c4n = CG(c4n2), total = CG(nX24), C2 = CP(Cin2);
+    const float* p2 = CP(x2);
+    const unsigned ldx2 = CP(ldx2);
+    for (int base = tid; base < total; base += 2 * nthr) {
+      f32x4 v[2];
+      int so[2] = {-1, -1}, sc[2] = {0, 0};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int idx = base + u * nthr;
+        if (idx < total) {
+          int row = dC4.div(idx), c4 = idx - row * c4n;
+          const int s2 = dLout.div(row);
+          so[u] = s2 * CS2 + (row - s2 * Lout) * ld2 + 4 * c4;
+          sc[u] = 4 * c4;
+          int left = row < nvs * Lout ? C2 - 4 * c4 : 0;
+          v[u] = load4<VEC>(p2 + ((unsigned)b0 * Lout + row) * ldx2 + 4 * c4, left);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (so[u] >= 0) {
+          if constexpr (BF) store4_bf16x2(slab2 + so[u] - sc[u], sc[u], 4 * c4n, v[u]);
+          else *(f32x4*)&slab2[so[u]] = v[u];
+        }
+    }
+  };
+
   // ---- stage everything this workgroup reads from global: all loads first, then the LDS writes ----
   if (active) {
     float c0 = 0.f, c1 = 1.f, c2 = 0.f, c3 = 0.f;
@@ -398,34 +436,7 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
         *(f32x4*)&slab[s * CS + j * ldA + 4 * c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
-    if (has2) {           // second source rows at the output positions -> slab2
-      const FastDiv dC4(CG(c4n2), CG(mC4b));
-      const int c4n = CG(c4n2), total = CG(nX24), C2 = CP(Cin2);
-      const float* p2 = CP(x2);
-      const unsigned ldx2 = CP(ldx2);
-      for (int base = tid; base < total; base += 2 * nthr) {
-        f32x4 v[2];
-        int so[2] = {-1, -1}, sc[2] = {0, 0};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          int idx = base + u * nthr;
-          if (idx < total) {
-            int row = dC4.div(idx), c4 = idx - row * c4n;
-            const int s2 = dLout.div(row);
-            so[u] = s2 * CS2 + (row - s2 * Lout) * ld2 + 4 * c4;
-            sc[u] = 4 * c4;
-            int left = row < nvs * Lout ? C2 - 4 * c4 : 0;
-            v[u] = load4<VEC>(p2 + ((unsigned)b0 * Lout + row) * ldx2 + 4 * c4, left);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (so[u] >= 0) {
-            if constexpr (BF) store4_bf16x2(slab2 + so[u] - sc[u], sc[u], 4 * c4n, v[u]);
-            else *(f32x4*)&slab2[so[u]] = v[u];
-          }
-      }
-    }
+    if (has2 && !x2late) stage_x2();
     if (haspro) {
       if (tid < S * GN_GROUPS * 2) pstat[tid] = psv;
       for (int i = tid + nthr; i < S * GN_GROUPS * 2; i += nthr) pstat[i] = ps_load(i);
@@ -684,6 +695,11 @@ __device__ __forceinline__ void conv_body(const DV& dv, const ConvPre pre, float
         first(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, G);
         first(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, G + 1);
       }
+    }
+    if (x2late && n2g > 0) {
+      __syncthreads();          // every wave is done with the first source's slab
+      stage_x2();
+      __syncthreads();
     }
     for (int Gs = 0; Gs < n2g; Gs += 2) {
       second(std::integral_constant<int, 0>{}, Gs);
@@ -993,6 +1009,7 @@ static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hip
   const float* w0 = L.p[0].w;
   const float* w1 = L.p[nz > 1 ? 1 : 0].w;
   static_assert(offsetof(ConvLaunch, p) == 0 && alignof(ConvLaunch) == 8, "descriptor offset in the kernel arguments");
+  if (g.x2late && (tl.bf || !vec)) return hipErrorInvalidValue;   // only the W5 kernel stages the second source late
   if (tl.bf) {
     // bf16x3: vector-addressable sources, whole 32-channel steps per tap and per wave, no fused backward prologue
     if (!vec || p.pro || (p.Cin_p & 31) || (p.x2 && (p.Cin2_p & 31)) || (g.chunk & 1) || (g.KK & 1)) return hipErrorInvalidValue;
@@ -1004,6 +1021,7 @@ static hipError_t launch_conv_t(const ConvLaunch& L, int nz, const Tile& tl, hip
     bool w5 = false;
     if constexpr (PM)
       w5 = conv_w5_ok(p, tl) && g.fhk == 2 && g.nv == p.Lout && g.KK1 == 5 * g.cbpt;
+    if (!w5 && g.x2late) return hipErrorInvalidValue;      // the LDS carve assumes the W5 kernel
     if (w5) {
       if constexpr (PM)
         hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, true, PM, false, true>), grid, block, lds, st, w0, w1, p.Npad, g.TN, g.NG,

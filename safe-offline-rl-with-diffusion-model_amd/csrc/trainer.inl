@@ -474,6 +474,7 @@ namespace {
 int launch_op(const Op& op, const Resolver& r, Tile tl, hipStream_t st) {
   ConvLaunch L{};
   L.p[0] = r.conv(op);
+  tl.bf = 0;                                     // the chooser's assumption; the operands decide
   if (use_bf(r.net, op, r.B) && conv_vec_ok(L.p[0])) {
     tl.bf = 1;
     L.p[0].w = op.w16;

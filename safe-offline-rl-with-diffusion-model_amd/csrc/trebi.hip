@@ -1009,6 +1009,7 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
           Tile t{MI, NI, NG, KS, S};
           t.pm = pm;
           t.resg = resg;
+          t.bf = bf;                                   // the LDS carve depends on it (conv_make_geo: x2late)
           double frac = 1.0;                          // share of (position, tap) pairs that touch real input rows
           int rows = R;
           static const char* dbg = getenv("TREBI_CHOOSER_DEBUG");          // diagnostics: layer-name substring
@@ -1047,9 +1048,7 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
           // (the channel-block-major loop of conv_w5_ok has neither the chain nor the branches; what it pays for is its
           // weight stream, so the eight-tile one-column waves, with half the requests per MFMA, come out ~10 % ahead of
           // the four-tile ones, which run as fast as the tap-major loop did: measured per layer at 8192 candidates)
-          t.bf = bf;
           const bool w5 = pm && conv_w5_ok(q, t);
-          t.bf = 0;                                    // the caller sets it once the operands are known to qualify
           const double pmk = pm ? (NI == 1 ? (w5 ? (MI == 8 ? 0.92 : 1.05) : 1.25) : 1.05) : 1.0;
           const double mfma = 32.0 * 4 * MI * NI * chunk * frac * pmk;     // cycles of one wave's matrix work
           const double simd = mfma * std::max(1.0, occ * NG * KS / 4.0);   // waves of a SIMD share its matrix core
@@ -1182,6 +1181,7 @@ int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, 
     if (tl.S * op.Lout > 16 * tl.MI || op.Npad % (16 * tl.NI * tl.NG) || 64 * tl.NG * tl.KS > 512 ||
         (op.pro && (op.stride != 1 || op.Lin != op.Lout)) || !L.p[0].x || !L.p[0].out)
       return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
+    tl.bf = 0;
     if (bf) {
       tl.bf = 1;
       L.p[0].w = op.w16;
@@ -1550,6 +1550,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
         (op.pro && (op.stride != 1 || op.Lin != op.Lout)) || !st.L.p[0].x || !st.L.p[0].out)
       return fail(TREBI_UNSUPPORTED_CONFIG, "internal tiling error at layer %s", op.name.c_str());
     st.flops = op.flops * B * nz;
+    st.tl.bf = 0;
     if (bf) {
       st.tl.bf = 1;
       st.L.p[0].w = op.w16;
