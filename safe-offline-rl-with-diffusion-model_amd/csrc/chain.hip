@@ -46,6 +46,7 @@ extern "C" int trebi_debug_read_cstamps(unsigned long long* out) {
 namespace {
 
 constexpr int WREG = 8;            // float4 weight registers per slot (8 reduction steps of one 16-column tile)
+constexpr int TABV = 4;            // float4 registers per thread that carry a chain's parameter table into LDS
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void drain_barrier() {
@@ -140,19 +141,18 @@ __device__ __forceinline__ void wblk(f32x4 (&w)[WREG], const float* pw, unsigned
 
 // Request the first weights of a stage: direct stages the first three blocks (a whole narrow layer), split-K
 // stages the first block of the wave's K range.  Issued a stage ahead, before the epilogue.
+// (DIRECT is the kernel's compile-time stage form; direct stages always have NI == 1 -- chain_tile, plan_direct_single:
+// with the form and NI decided at run time both request sequences were compiled into every kernel and the registers they
+// share were merged with copies behind vmcnt(0) waits.)
+template <bool DIRECT>
 __device__ __forceinline__ void wprefetch(const WInfo& q, int wave, int lane, f32x4 (&w)[3][WREG]) {
   if (wave >= q.NG * q.KS) return;
   const int ks = FastDiv(q.NG, q.mNG).div(wave), ng = wave - ks * q.NG;
   const unsigned wlane = (unsigned)(((lane >> 4) * q.Npad + q.n0 + ng * q.NI * 16 + (lane & 15)) * 4);
   const unsigned wstep = (unsigned)q.Npad * 16u;
-  if (q.direct) {
-    if (q.NI == 1) {
+  if constexpr (DIRECT) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) wblk<1>(w[i], q.w, wstep, wlane, blk_of(i, 3, q.KK1, q.KK));
-    } else {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) wblk<2>(w[i], q.w, wstep, wlane, blk_of(i, 2, q.KK1, q.KK));
-    }
+    for (int i = 0; i < 3; ++i) wblk<1>(w[i], q.w, wstep, wlane, blk_of(i, 3, q.KK1, q.KK));
     return;
   }
   const int kb = ks * q.chunk;
@@ -176,7 +176,8 @@ __device__ __forceinline__ f32x4 ld4(const float* sp, int left, bool vec) {
 template <int MI, int NI, bool DIRECT>
 __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool has_next, float* smem, const int tid,
                                          const int b0, int t_uniform, const long long* tptr,
-                                         f32x4 (&wreg)[3][WREG], int skey, int sidx) {
+                                         f32x4 (&wreg)[3][WREG], int skey, int sidx, const float* ptab, const int parN,
+                                         const f32x4 (&tabv)[TABV], float* tabdst, const int tabn4) {
   constexpr int WH = WREG / NI;    // reduction steps per register slot
   CSTAMP(0);
   const int lane = tid & 63;
@@ -257,7 +258,6 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
   // in that lane's registers.
   float c0 = 0.f, c1 = 1.f, c2 = 0.f, c3 = 0.f;
   float tbv[2] = {0.f, 0.f};
-  float dbias[NI], dgam[NI], dbet[NI], dbi2[NI], dtb[NI][4];
   // direct: rows 4*g + q of the wave's 16-row tile -> (candidate, position)
   int sq[4], loq[4];
   bool vq[4];
@@ -277,28 +277,6 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
     return gld(DP(tbias) + (unsigned)tt * (unsigned)N + c);
   };
   if (active) {
-    if (DIRECT) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + (ng * NI + ni) * 16 + lr;
-        const bool ok = n < N;
-        dbias[ni] = (ok && DP(bias)) ? gld(DP(bias) + n) : 0.f;
-        dgam[ni] = (ok && hasgn) ? gld(DP(gamma) + n) : 1.f;
-        dbet[ni] = (ok && hasgn) ? gld(DP(beta) + n) : 0.f;
-        dbi2[ni] = (ok && DP(bias2)) ? gld(DP(bias2) + n) : 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          dtb[ni][q] = 0.f;
-          if (ok && hastb && (q == 0 || (t_uniform < 0 && Lout < 4))) {       // one time row per candidate
-            long long tt = t_uniform >= 0 ? t_uniform : (sq[q] < nvs ? gldll(tptr + b0 + sq[q]) : 0);
-            tt = tt < 0 ? 0 : (tt >= DP(T) ? DP(T) - 1 : tt);
-            dtb[ni][q] = gld(DP(tbias) + (unsigned)tt * (unsigned)N + n);
-          } else if (q > 0) {
-            dtb[ni][q] = dtb[ni][0];
-          }
-        }
-      }
-    }
     if (colt) {
       const int n = tid;
       const bool ok = n < N;
@@ -394,7 +372,12 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
     }
   }
   CSTAMP(1);
-  if ((!DS(srcRes) && !DS(proRes)) || (has2 && !DS(x2Res))) lds_barrier();     // staged operands visible to every wave
+  if (tabn4 > 0) {                 // first stage of a direct chain: the parameter table requested at kernel start
+#pragma unroll
+    for (int k = 0; k < TABV; ++k)
+      if (tid + 512 * k < tabn4) *(f32x4*)&tabdst[4 * (tid + 512 * k)] = tabv[k];
+  }
+  if (tabn4 > 0 || (!DS(srcRes) && !DS(proRes)) || (has2 && !DS(x2Res))) lds_barrier();     // staged operands visible to every wave
 
   // ---- prologue: GroupNorm backward of the producing Conv1dBlock ----------------------------------
   //   d = dA * mish'(z)*gamma;  dY = rstd * (d - mean_g(d) - xhat * mean_g(d * xhat))
@@ -631,7 +614,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
   }
   CSTAMP(3);
   // the next stage's first weight block travels while this stage reduces and normalises
-  if (has_next) wprefetch(winfo_of(dvn), wave, lane, wreg);
+  if (has_next) wprefetch<DIRECT>(winfo_of(dvn), wave, lane, wreg);
 
   const int kstride = TM * TNp;
   if (!DIRECT) {
@@ -670,6 +653,16 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
     const bool xchg = hasgn && (two || twoc);
     float v[NI][4], ml[NI][4], m2[NI][4];
     int cols[NI];
+    // per-column parameters: this chain's LDS table [stage][bias, gamma, beta, time bias, bias2][parN], filled at
+    // kernel start from the table the host built per (net, timestep).  (They used to be global loads issued at the
+    // top of the stage: consuming them here made the epilogue wait -- vmcnt retires in order -- for the next
+    // stage's 24 weight requests issued in between.)
+    float dbias[NI], dgam[NI], dbet[NI], dbi2[NI], dtb[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const float* pc = ptab + n0 + (ng * NI + ni) * 16 + lr;
+      dbias[ni] = pc[0]; dgam[ni] = pc[parN]; dbet[ni] = pc[2 * parN]; dtb[ni] = pc[3 * parN]; dbi2[ni] = pc[4 * parN];
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       cols[ni] = n0 + (ng * NI + ni) * 16 + lr;
@@ -777,7 +770,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
             }
             val = a;
           }
-          val += dtb[ni][q];
+          val += dtb[ni];
           if (has2) val += acc2[0][ni][q] + dbi2[ni];
           if (hasres) val += resb[(sw * RbR + hR + lo) * ldR + col - n0];
           const int pos = osplit > 0 ? 2 * lo + ph : lo;
@@ -922,23 +915,39 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
 // footprint within two waves per SIMD without spilling).
 template <bool DIRECT>
 __global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __restrict__ stages, int nstages,
-                                                             int t_uniform, const long long* tptr) {
+                                                             int t_uniform, const long long* tptr,
+                                                             const float* __restrict__ cpar, int parN, int parT, int oTab) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4 wreg[3][WREG];
   const int z = blockIdx.z, tid = threadIdx.x;
+  // Direct chains: the per-column parameters of ALL stages at this timestep are one contiguous block per (net, t) of a
+  // table the host built with the launch plan ([z][t][stage][bias, gamma, beta, time bias, bias2][parN]); requested
+  // here, carried in registers past the first stage's own requests and written to LDS in front of its first barrier.
+  f32x4 tabv[TABV];
+  int tabn4 = 0;
+  float* tabdst = smem + oTab;
+  if (DIRECT) {
+    tabn4 = nstages * 5 * parN / 4;
+    const int tt = t_uniform < 0 ? 0 : (t_uniform >= parT ? parT - 1 : t_uniform);
+    const float* src = cpar + (size_t)(z * parT + tt) * (size_t)(4 * tabn4);
+#pragma unroll
+    for (int k = 0; k < TABV; ++k)
+      if (tid + 512 * k < tabn4) tabv[k] = gld4(src + 4 * (tid + 512 * k));
+  }
   const int skey = (nstages < 48 ? nstages : 47) * 2 + (gridDim.z - 1);
   (void)skey;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   DV dv, dvn;
   dload(dv, stages, z, lane);
   dvn = dv;
-  wprefetch(winfo_of(dv), wave, lane, wreg);
+  wprefetch<DIRECT>(winfo_of(dv), wave, lane, wreg);
   for (int i = 0; i < nstages; ++i) {
     const bool has_next = i + 1 < nstages;
     if (has_next) dload(dvn, stages + i + 1, z, lane);      // consumed a whole stage later
     const int b0 = blockIdx.x * DG(S);
     if (DS(drain)) drain_barrier();
-#define RC_ARGS dv, dvn, has_next, smem, tid, b0, t_uniform, tptr, wreg, skey, i
+#define RC_ARGS dv, dvn, has_next, smem, tid, b0, t_uniform, tptr, wreg, skey, i, tabdst + i * 5 * parN, parN, tabv, tabdst, \
+                (DIRECT && i == 0) ? tabn4 : 0
     if (DIRECT) {
       rc_stage<1, 1, true>(RC_ARGS);
     } else {
@@ -958,6 +967,27 @@ __global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __res
   }
 }
 
+// One stage's rows of a direct chain's parameter table, for every timestep: dst + t * t_stride holds
+// [bias | gamma | beta | time-bias row of t | bias2][parN] (0, 1, 0, 0, 0 where the layer has none / past N).
+__global__ void chain_params_kernel(const float* bias, const float* gamma, const float* beta, const float* tbias,
+                                    const float* bias2, int N, int parN, float* dst, size_t t_stride) {
+  const int t = blockIdx.x;
+  float* d = dst + (size_t)t * t_stride;
+  for (int n = threadIdx.x; n < parN; n += blockDim.x) {
+    const bool ok = n < N;
+    d[n] = (ok && bias) ? bias[n] : 0.f;
+    d[parN + n] = (ok && gamma) ? gamma[n] : 1.f;
+    d[2 * parN + n] = (ok && beta) ? beta[n] : 0.f;
+    d[3 * parN + n] = (ok && tbias) ? tbias[(size_t)t * N + n] : 0.f;
+    d[4 * parN + n] = (ok && bias2) ? bias2[n] : 0.f;
+  }
+}
+hipError_t launch_chain_params(const ConvP& p, float* dst, int parN, int T, size_t t_stride, hipStream_t st) {
+  hipLaunchKernelGGL(chain_params_kernel, dim3(T), dim3(64), 0, st, p.bias, p.gn ? p.gamma : nullptr,
+                     p.gn ? p.beta : nullptr, p.tbias, p.bias2, p.N, parN, dst, t_stride);
+  return hipGetLastError();
+}
+
 bool chain_variant_ok(int MI, int NI) {
   return (NI == 1 && (MI == 1 || MI == 2)) || (NI == 2 && MI == 1);
 }
@@ -972,13 +1002,15 @@ hipError_t chain_init_device() {
 }
 
 hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, int ny, size_t lds_bytes,
-                        int t_uniform, const long long* t, hipStream_t st) {
-  if (direct)
+                        int t_uniform, const long long* t, const float* cpar, int parN, int parT, int oTab, hipStream_t st) {
+  if (direct) {
+    // the parameter table is indexed by the launch's (uniform) timestep and must fit the registers that carry it
+    if (!cpar || t_uniform < 0 || parN < 16 || (parN & 15) || nstages * 5 * parN > 4 * 512 * TABV) return hipErrorInvalidValue;
     hipLaunchKernelGGL(resident_chain_kernel<true>, dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,
-                       nstages, t_uniform, t);
-  else
+                       nstages, t_uniform, t, cpar, parN, parT, oTab);
+  } else
     hipLaunchKernelGGL(resident_chain_kernel<false>, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages,
-                       nstages, t_uniform, t);
+                       nstages, t_uniform, t, cpar, parN, parT, oTab);
   return hipGetLastError();
 }
 

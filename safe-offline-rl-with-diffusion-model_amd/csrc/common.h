@@ -123,8 +123,12 @@ bool conv_w5_ok(const ConvP& p, const Tile& tl);     // the layer / tile pairs t
 bool conv_vec_ok(const ConvP& p);
 bool chain_variant_ok(int MI, int NI);
 hipError_t chain_init_device();
+// cpar: per-column parameter table of a direct chain, [nz][parT][nstages][5][parN] floats (bias, gamma, beta, time-bias row,
+// bias2; defaults 0,1,0,0,0 past N), filled by launch_chain_params; oTab: float offset of its LDS copy.
 hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, int ny, size_t lds_bytes,
-                        int t_uniform, const long long* t, hipStream_t st);
+                        int t_uniform, const long long* t, const float* cpar, int parN, int parT, int oTab, hipStream_t st);
+hipError_t launch_chain_params(const ConvP& p, float* dst /* + ((z*T + t)*nstages + stage)*5*parN */, int parN, int T,
+                               size_t t_stride, hipStream_t st);
 
 // Value head (temporal.py:237-238) forward + the seed of the backward.
 struct HeadP {

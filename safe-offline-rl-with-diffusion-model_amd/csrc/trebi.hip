@@ -1219,10 +1219,28 @@ struct PlanStep {
   int nz = 1;
   int chain_off = 0, chain_n = 0, nblocks = 0, chain_direct = 0, ny = 1;
   size_t chain_lds = 0;
+  size_t par_off = 0;              // direct chains: float offset of the parameter table in the sampler's table arena
+  int parN = 0, parT = 0, oTab = 0;
   double flops = 0;                // algorithmic, whole batch, all nets of the launch
   std::string name;
 };
 typedef std::vector<PlanStep> Plan;
+
+// Per-column parameter tables of the direct chains of a set of plans (common.h, launch_chain): what to fill and where.
+struct ParTab {
+  struct Fill { ConvP p; size_t off; int parN; size_t t_stride; };
+  std::vector<Fill> fills;
+  size_t floats = 0;
+  // reserve [nz][T][nstages][5][parN] for a chain and queue the fills of its stages
+  size_t add(const std::vector<RStage>& run, int nz, int parN, int T) {
+    const size_t base = floats, n = run.size(), t_stride = n * 5 * (size_t)parN;
+    for (int z = 0; z < nz; ++z)
+      for (size_t k = 0; k < n; ++k)
+        fills.push_back({run[k].p[z], base + ((size_t)z * T * n + k) * 5 * parN, parN, t_stride});
+    floats += (size_t)nz * T * t_stride;
+    return base;
+  }
+};
 
 int pow2ceil(int v) { int r = 1; while (r < v) r *= 2; return r; }
 
@@ -1283,7 +1301,7 @@ bool chain_tile(const Op& op, int S, int max_n, Tile* out, bool* direct) {
 
 // Try to fold ops [i, ...) into one resident-chain launch; returns the number of ops folded (0: none).
 size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>& o1, size_t i, const Resolver& r0,
-                  const Resolver* r1, int B, int S, int max_n, std::vector<RStage>& tab, Plan& plan) {
+                  const Resolver* r1, int B, int S, int max_n, std::vector<RStage>& tab, ParTab& par, Plan& plan) {
   const int nz = r1 ? 2 : 1;
   std::vector<Tile> tiles;
   std::vector<char> directs;
@@ -1428,7 +1446,12 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
     const size_t oSlab = nreg * regsz, oSlab2 = oSlab + r4(slabsz), oRest = oSlab2 + r4(slab2sz),
                  oRed = oRest + r4(restsz), oRed2 = oRed + r4(redsz), oCol = oRed2 + r4(red2sz),
                  oTb = oCol + r4(colsz), total = oTb + r4(tbsz);
-    if (total * sizeof(float) > 160 * 1024) continue;
+    // direct chains: LDS copy of the per-column parameter table behind everything else
+    int parN = 16;
+    for (size_t k = 0; k < n; ++k) parN = std::max(parN, o0[i + k]->Npad);
+    const size_t tabsz = directs[0] ? n * 5 * (size_t)parN : 0;
+    if (tabsz > 8192) continue;                                    // what the kernel's registers carry (chain.hip TABV)
+    if ((total + tabsz) * sizeof(float) > 160 * 1024) continue;
     for (auto& st : run) {
       st.oSrc = st.srcRes ? (int)(st.oSrc * regsz) : (int)oSlab;
       st.oPro = st.proRes ? (int)(st.oPro * regsz) : 0;
@@ -1441,7 +1464,11 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
     ps.kind = 2; ps.nz = nz;
     ps.chain_off = (int)tab.size(); ps.chain_n = (int)n; ps.chain_direct = directs[0];
     ps.nblocks = (B + S - 1) / S;
-    ps.chain_lds = total * sizeof(float); ps.flops = fl;
+    ps.chain_lds = (total + tabsz) * sizeof(float); ps.flops = fl;
+    if (directs[0]) {
+      ps.parN = parN; ps.parT = run[0].p[0].T; ps.oTab = (int)total;
+      ps.par_off = par.add(run, nz, parN, ps.parT);
+    }
     ps.name = std::string(directs[0] ? "direct " : "") + "chain[" + std::to_string(n) + "] S" + std::to_string(S) + " " + o0[i]->name + " .. " + o0[j - 1]->name;
     tab.insert(tab.end(), run.begin(), run.end());
     plan.push_back(ps);
@@ -1453,7 +1480,7 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
 // A single layer as a one-stage direct launch: workgroups own MS row tiles x NG column tiles of 16x16,
 // one wave per tile over the whole reduction, grid = (candidate groups, column tiles, nets).
 bool plan_direct_single(const Op& op, const Op* op1, const Resolver& r0, const Resolver* r1, int B,
-                        std::vector<RStage>& tab, Plan& plan) {
+                        std::vector<RStage>& tab, ParTab& par, Plan& plan) {
   static const bool allow = getenv("TREBI_DIRECT_SINGLE") && atoi(getenv("TREBI_DIRECT_SINGLE")) != 0;   // experimental: the split-K kernel is still faster for wide layers
   static const int max_b = getenv("TREBI_DIRECT_MAXB") ? atoi(getenv("TREBI_DIRECT_MAXB")) : 256;
   if (!allow || B > max_b || op.kind != 0 || op.Npad % 16) return false;
@@ -1495,13 +1522,17 @@ bool plan_direct_single(const Op& op, const Op* op1, const Resolver& r0, const R
   st.dstRes = 0; st.oD = 0; st.RbD = 1; st.ldD = 4; st.Ld = 0; st.mLd4 = 0;
   st.oRed = (int)(slab + slab2 + rest); st.oRed2 = st.oRed; st.oColp = st.oRed; st.oTb = st.oRed;
   const size_t total = slab + slab2 + rest + xch;
-  if (total * sizeof(float) > 160 * 1024) return false;
+  const int parN = op.Npad;
+  const size_t tabsz = 5 * (size_t)parN;
+  if ((total + tabsz) * sizeof(float) > 160 * 1024 || tabsz > 8192) return false;
   PlanStep ps;
   ps.kind = 2; ps.nz = nz;
   ps.chain_off = (int)tab.size(); ps.chain_n = 1; ps.chain_direct = 1;
   ps.nblocks = (B + S - 1) / S;
   ps.ny = op.Npad / (16 * NG);
-  ps.chain_lds = total * sizeof(float);
+  ps.chain_lds = (total + tabsz) * sizeof(float);
+  ps.parN = parN; ps.parT = st.p[0].T; ps.oTab = (int)total;
+  ps.par_off = par.add(std::vector<RStage>{st}, nz, parN, ps.parT);
   ps.flops = op.flops * B * nz;
   char tb[96];
   snprintf(tb, sizeof tb, " direct MS%d NG%d S%d grid %dx%d", MS, NG, S, ps.nblocks, ps.ny);
@@ -1513,7 +1544,7 @@ bool plan_direct_single(const Op& op, const Op* op1, const Resolver& r0, const R
 
 int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vector<const std::vector<Op>*>& lists1,
                const Resolver& r0, const Resolver* r1, int B, bool want_grad, int chain_S, int chain_max_n,
-               std::vector<RStage>& tab, Plan& plan) {
+               std::vector<RStage>& tab, ParTab& par, Plan& plan) {
   const int nz = r1 ? 2 : 1;
   std::vector<const Op*> o0, o1;
   for (auto* l : lists0) for (auto& op : *l) o0.push_back(&op);
@@ -1532,10 +1563,10 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
       continue;
     }
     if (chain_S > 0) {
-      size_t n = plan_chain(o0, o1, i, r0, r1, B, chain_S, chain_max_n, tab, plan);
+      size_t n = plan_chain(o0, o1, i, r0, r1, B, chain_S, chain_max_n, tab, par, plan);
       if (n) { i += n; continue; }
     }
-    if (plan_direct_single(op, r1 ? o1[i] : nullptr, r0, r1, B, tab, plan)) { ++i; continue; }
+    if (plan_direct_single(op, r1 ? o1[i] : nullptr, r0, r1, B, tab, par, plan)) { ++i; continue; }
     PlanStep st;
     st.kind = 0; st.nz = nz;
     st.L.p[0] = r0.conv(op);
@@ -1568,8 +1599,8 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
   return 0;
 }
 
-int exec_plan(const Plan& plan, const RStage* dev_tab, int t_uniform, const long long* tptr, hipStream_t st,
-              GemmProfile* prof) {
+int exec_plan(const Plan& plan, const RStage* dev_tab, const float* dev_par, int t_uniform, const long long* tptr,
+              hipStream_t st, GemmProfile* prof) {
   for (const PlanStep& ps : plan) {
     if (ps.kind == 1) {
       HeadLaunch H = ps.H;
@@ -1588,7 +1619,8 @@ int exec_plan(const Plan& plan, const RStage* dev_tab, int t_uniform, const long
       HIPCHK(hipEventRecord(prof->ev[prof->used].first, st));
     }
     if (ps.kind == 2) {
-      HIPCHK(launch_chain(dev_tab + ps.chain_off, ps.chain_n, ps.chain_direct, ps.nz, ps.nblocks, ps.ny, ps.chain_lds, t_uniform, tptr, st));
+      HIPCHK(launch_chain(dev_tab + ps.chain_off, ps.chain_n, ps.chain_direct, ps.nz, ps.nblocks, ps.ny, ps.chain_lds, t_uniform, tptr,
+                          dev_par + ps.par_off, ps.parN, ps.parT, ps.oTab, st));
     } else {
       ConvLaunch L = ps.L;
       for (int z = 0; z < ps.nz; ++z) { L.p[z].t = tptr; L.p[z].t_uniform = t_uniform; }
@@ -1970,11 +2002,14 @@ struct trebi_sampler {
   Plan unet_plan;
   RStage* dev_tab = nullptr;
   size_t dev_tab_cap = 0;
+  float* dev_par = nullptr;         // per-column parameter tables of the direct chains (ParTab)
+  size_t dev_par_cap = 0;
   const void* plan_key[3] = {};
   bool plans_valid = false;
   bool bound = false;               // trebi_sampler_bind succeeded for the pointers in `key`
   ~trebi_sampler() {
     if (dev_tab) (void)hipFree(dev_tab);
+    if (dev_par) (void)hipFree(dev_par);
     if (exec) (void)hipGraphExecDestroy(exec);
     if (arena) (void)hipFree(arena);
     if (ev_a) (void)hipEventDestroy(ev_a);
@@ -2059,11 +2094,12 @@ static int ensure_plans(trebi_sampler* s, float* x, float* values, float* costs)
   const int chain_S = (e_chain && atoi(e_chain) == 0) || B > chain_max_b ? 0 : (e_cs ? atoi(e_cs) : (B <= 160 ? 1 : B <= 448 ? 2 : 4));
   const int chain_max_n = e_maxn ? atoi(e_maxn) : 64;
   std::vector<RStage> tab;
+  ParTab par;
   s->vf_grad.clear(); s->vf_nograd.clear(); s->unet_plan.clear();
   Binding bu;
   bu.x = x; bu.ldx = D; bu.out = s->x0; bu.ldo = D; bu.ws = s->ws_u;
   Resolver ru{s->unet, s->unet->offsets(B), bu, B};
-  if (int e = build_plan({&s->unet->fwd}, {}, ru, nullptr, B, false, chain_S, chain_max_n, tab, s->unet_plan)) return e;
+  if (int e = build_plan({&s->unet->fwd}, {}, ru, nullptr, B, false, chain_S, chain_max_n, tab, par, s->unet_plan)) return e;
   if (s->reward) {
     Binding br, bc;
     br.x = x; br.ldx = D; br.grad = s->rgrad; br.ldg = D; br.ws = s->ws_r; br.y = values;
@@ -2074,20 +2110,20 @@ static int ensure_plans(trebi_sampler* s, float* x, float* values, float* costs)
       if (s->dual) {
         s->vf_grad.resize(1); s->vf_nograd.resize(1);
         if (int e = build_plan({&s->cost->fwd, &s->cost->bwd}, {&s->reward->fwd, &s->reward->bwd}, rc, &rr, B, true,
-                               chain_S, chain_max_n, tab, s->vf_grad[0])) return e;
-        if (int e = build_plan({&s->cost->fwd}, {&s->reward->fwd}, rc, &rr, B, false, chain_S, chain_max_n, tab,
+                               chain_S, chain_max_n, tab, par, s->vf_grad[0])) return e;
+        if (int e = build_plan({&s->cost->fwd}, {&s->reward->fwd}, rc, &rr, B, false, chain_S, chain_max_n, tab, par,
                                s->vf_nograd[0])) return e;
       } else {
         s->vf_grad.resize(2); s->vf_nograd.resize(2);
-        if (int e = build_plan({&s->cost->fwd, &s->cost->bwd}, {}, rc, nullptr, B, true, chain_S, chain_max_n, tab, s->vf_grad[0])) return e;
-        if (int e = build_plan({&s->cost->fwd}, {}, rc, nullptr, B, false, chain_S, chain_max_n, tab, s->vf_nograd[0])) return e;
-        if (int e = build_plan({&s->reward->fwd, &s->reward->bwd}, {}, rr, nullptr, B, true, chain_S, chain_max_n, tab, s->vf_grad[1])) return e;
-        if (int e = build_plan({&s->reward->fwd}, {}, rr, nullptr, B, false, chain_S, chain_max_n, tab, s->vf_nograd[1])) return e;
+        if (int e = build_plan({&s->cost->fwd, &s->cost->bwd}, {}, rc, nullptr, B, true, chain_S, chain_max_n, tab, par, s->vf_grad[0])) return e;
+        if (int e = build_plan({&s->cost->fwd}, {}, rc, nullptr, B, false, chain_S, chain_max_n, tab, par, s->vf_nograd[0])) return e;
+        if (int e = build_plan({&s->reward->fwd, &s->reward->bwd}, {}, rr, nullptr, B, true, chain_S, chain_max_n, tab, par, s->vf_grad[1])) return e;
+        if (int e = build_plan({&s->reward->fwd}, {}, rr, nullptr, B, false, chain_S, chain_max_n, tab, par, s->vf_nograd[1])) return e;
       }
     } else {
       s->vf_grad.resize(1); s->vf_nograd.resize(1);
-      if (int e = build_plan({&s->reward->fwd, &s->reward->bwd}, {}, rr, nullptr, B, true, chain_S, chain_max_n, tab, s->vf_grad[0])) return e;
-      if (int e = build_plan({&s->reward->fwd}, {}, rr, nullptr, B, false, chain_S, chain_max_n, tab, s->vf_nograd[0])) return e;
+      if (int e = build_plan({&s->reward->fwd, &s->reward->bwd}, {}, rr, nullptr, B, true, chain_S, chain_max_n, tab, par, s->vf_grad[0])) return e;
+      if (int e = build_plan({&s->reward->fwd}, {}, rr, nullptr, B, false, chain_S, chain_max_n, tab, par, s->vf_nograd[0])) return e;
     }
   }
   if (tab.size() > s->dev_tab_cap) {
@@ -2097,6 +2133,14 @@ static int ensure_plans(trebi_sampler* s, float* x, float* values, float* costs)
     HIPCHK(hipMalloc((void**)&s->dev_tab, s->dev_tab_cap * sizeof(RStage)));
   }
   if (!tab.empty()) HIPCHK(hipMemcpy(s->dev_tab, tab.data(), tab.size() * sizeof(RStage), hipMemcpyHostToDevice));
+  if (par.floats > s->dev_par_cap) {
+    if (s->dev_par) (void)hipFree(s->dev_par);
+    s->dev_par = nullptr;
+    s->dev_par_cap = par.floats + 1024;
+    HIPCHK(hipMalloc((void**)&s->dev_par, s->dev_par_cap * sizeof(float)));
+  }
+  for (const auto& f : par.fills) HIPCHK(launch_chain_params(f.p, s->dev_par + f.off, f.parN, f.p.T, f.t_stride, 0));
+  HIPCHK(hipDeviceSynchronize());
   memcpy(s->plan_key, key, sizeof key);
   s->plans_valid = true;
   return 0;
@@ -2128,7 +2172,7 @@ static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const
         for (int k = 0; k < d.n_guide_steps; ++k) {
           const bool grad = !stopped;
           for (const Plan& pl : (grad ? s->vf_grad : s->vf_nograd))
-            if (int e = exec_plan(pl, s->dev_tab, i, t, st, prof)) return e;
+            if (int e = exec_plan(pl, s->dev_tab, s->dev_par, i, t, st, prof)) return e;
           if (grad)
             HIPCHK(launch_guide_update(sp, x, s->rgrad, s->cost ? s->cgrad : nullptr, costs, thr, t, s->plv, B, st));
           else if (d.skip_dead_evals)
@@ -2136,7 +2180,7 @@ static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const
         }
       }
     }
-    if (int e = exec_plan(s->unet_plan, s->dev_tab, i, t, st, prof)) return e;
+    if (int e = exec_plan(s->unet_plan, s->dev_tab, s->dev_par, i, t, st, prof)) return e;
     float* ch = chain ? chain + (size_t)(T - i) * per : nullptr;
     HIPCHK(launch_ddpm_update(sp, x, s->x0, noise + (size_t)(T - i) * per, t, s->plv, s->c1, s->c2, B, ch, st));
   }
