@@ -34,6 +34,16 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 matrix peak (no sparsity)
 
 
+def gflop_per_trajectory(F_unet, F_vf_fwd, F_vf_bwd, n_guide_steps, t_stopgrad, n_nets=2):
+    """(nominal, executed) algorithmic GFLOP per trajectory of one planning call.  Nominal = SURVEY.md 8d's formula
+    T x (F_unet + n_nets x n_guide_steps x (F_fwd + F_bwd)); executed = the same minus the value-net backward passes of
+    the denoise steps with t < t_stopgrad, whose gradient the reference zeroes by assignment (functions.py:116) and the
+    captured loop therefore does not compute (enqueue_loop in csrc/trebi.hip).  Every `frac` in the line uses EXECUTED."""
+    nominal = T * (F_unet + n_nets * n_guide_steps * (F_vf_fwd + F_vf_bwd))
+    executed = nominal - min(t_stopgrad, T) * n_nets * n_guide_steps * F_vf_bwd
+    return nominal / 1e9, executed / 1e9
+
+
 def _coll_device(device):
     """Tensors of the bench's own tiny collectives: on the GPU for RCCL (it needs device tensors), on the host for gloo
     (the one-GPU rehearsal; gloo's device-tensor path stalled intermittently with two processes on one GPU)."""
@@ -127,11 +137,14 @@ def other_configs(device, steps=3, world=1, rank=0, rehearse=False):
         dt = (time.perf_counter() - t0) / steps
         if world > 1:
             dt = _max_over_ranks(dt, device)
-        fl = T * (unet.flops() + 2 * kw['n_guide_steps'] * (guide._net().flops() + guide._net().flops(backward=True)))
+        g_nom, g_exe = gflop_per_trajectory(unet.flops(), guide._net().flops(), guide._net().flops(backward=True),
+                                            kw['n_guide_steps'], kw['t_stopgrad'])
+        fl = g_exe * 1e9
         tf = fl * n_global / dt / 1e12
         entry = {'workload': f'{name}: {n_global} candidates over {world} GPU(s), {B} on this rank',
                  'trajectories_per_s': n_global / dt, 'ms_per_step': 1e3 * dt, 'scaling': 'strong' if world > 1 else 'per-GPU size',
-                 'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS * world, 'unit': 'TFLOP/s',
+                 'algorithmic_gflop_per_trajectory': g_nom, 'executed_gflop_per_trajectory': g_exe,
+                 'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS * world, 'unit': 'TFLOP/s (executed FLOPs)',
                  'frac': tf / (PEAK_F32_MFMA_TFLOPS * world)}
         # the same call with the opt-in bf16x3 operands (engaged from 512 candidates per launch up), reported apart
         for net in (unet, guide._net(), cguide._net()):
@@ -363,7 +376,14 @@ def variants(diff, planner, obs, n_global, guide, cguide, thr, device, world, st
             dist.barrier()
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t0) / steps
-        out.append({'variant': label, 'trajectories_per_s': n_global / dt, 'ms_per_step': 1e3 * dt})
+        F_v = guide._net()
+        g_nom, g_exe = gflop_per_trajectory(diff.model.flops(), F_v.flops(), F_v.flops(backward=True), kw['n_guide_steps'],
+                                            kw['t_stopgrad'])
+        tf = g_exe * 1e9 * n_global / dt / 1e12
+        out.append({'variant': label, 'trajectories_per_s': n_global / dt, 'ms_per_step': 1e3 * dt,
+                    'algorithmic_gflop_per_trajectory': g_nom, 'executed_gflop_per_trajectory': g_exe,
+                    'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS * world, 'unit': 'TFLOP/s (executed FLOPs)',
+                    'frac': tf / (PEAK_F32_MFMA_TFLOPS * world)})
     return out
 
 
@@ -472,10 +492,9 @@ def main():
 
     phase('report')
     if rank == 0:
-        F_unet = diff.model.flops()
-        F_vf = guide._net().flops() + guide._net().flops(backward=True)
-        ngs, ts = PLAN_KW['n_guide_steps'], PLAN_KW['t_stopgrad']
-        gflop_nominal = T * (F_unet + 2 * ngs * F_vf) / 1e9              # SURVEY.md 8d formula
+        gflop_nominal, gflop_executed = gflop_per_trajectory(diff.model.flops(), guide._net().flops(),
+                                                             guide._net().flops(backward=True), PLAN_KW['n_guide_steps'],
+                                                             PLAN_KW['t_stopgrad'])
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # figure is the committed rocprofv3 --pmc measurement of this same command (profiles/, tools/analyze_traffic.py)
         traffic = None
@@ -501,7 +520,9 @@ def main():
                                    'TemporalUnet/ValueFunction dim_mults (1,2,4,8)',
                        'candidates_per_gpu': B, 'global_candidates': n_global,
                        'parallelism': f'candidate-sharded x{world}', 'skip_dead_evals': bool(args.skip_dead_evals),
-                       'algorithmic_gflop_per_trajectory': gflop_nominal},
+                       'algorithmic_gflop_per_trajectory': gflop_nominal,          # SURVEY.md 8d formula
+                       'executed_gflop_per_trajectory': gflop_executed,            # what roofline.achieved counts
+                       'whole_call_tflops_executed': gflop_executed * 1e9 * n_global * args.steps / dt / 1e12},
             'roofline': {'bound': 'mfma',
                          'kernel': 'implicit-GEMM Conv1d on f32 MFMA (conv_gemm_kernel + resident_chain_kernel)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

@@ -101,7 +101,9 @@ ConvGeo conv_make_geo(const ConvP& p, const Tile& tl) {
   // source is staged into the slab's space THEN (one exposed staging pass, two barriers) instead of next to it: 16
   // candidates of the 256-channel backward layers and 32 of the forward ones fit the 160 KB that way.
   static const bool late_on = !(getenv("TREBI_X2LATE") && atoi(getenv("TREBI_X2LATE")) == 0);
-  g.x2late = (late_on && p.x2 && n2 <= nA && conv_w5_ok(p, tl)) ? 1 : 0;
+  // (only where the W5 kernel WILL be launched: it exists for vector-addressable sources only -- launch_conv_t -- so the
+  // carve may not assume it for a source like the caller's x with a row stride of 23 floats)
+  g.x2late = (late_on && p.x2 && n2 <= nA && conv_w5_ok(p, tl) && conv_vec_ok(p)) ? 1 : 0;
   g.oSlab2 = g.x2late ? 0 : nA;
   if (g.x2late) n2 = 0;
   g.oY = nA + n2;

@@ -354,48 +354,69 @@ hipError_t launch_feasibility(const float* ry, const float* cy, const float* thr
   return hipGetLastError();
 }
 
-// Descending rank by counting: rank(i) = #{j : v[j] > v[i] or (v[j] == v[i] and j < i)}.
-// NaNs compare false everywhere, so they are ordered among themselves by index after every number.
-__global__ __launch_bounds__(256) void argsort_desc_kernel(const float* v, int n, long long* order) {
-  __shared__ float tile[256];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const float vi = i < n ? v[i] : 0.f;
-  const bool nan_i = vi != vi;
+// Descending rank by counting: rank(i) = #{j : v[j] sorts before v[i]}, ties by index.  NaN sorts before every number,
+// as in torch.argsort(descending=True) (the reference's sort_by_values, diffusion.py:44-49: NaN counts as the largest
+// value), NaNs among themselves by index.  Every value becomes ONE 64-bit key -- the order-preserving integer image of
+// the float (-0 folded onto +0, every NaN onto the top) above the inverted index -- so "j sorts before i" is a single
+// unsigned compare.  O(n^2) compares: a workgroup ranks 256 values, its four quarters each sweep a quarter of the tiles
+// (the all-gathered 65536 scores of configs[3]: 8.2 ms with the float compares of round 2, see DESIGN).
+__device__ __forceinline__ unsigned long long sort_key(float v, int idx) {
+  v += 0.f;                                           // -0 -> +0: equal to +0 like the float compare
+  unsigned u = __float_as_uint(v);
+  u = (v != v) ? 0xFFFFFFFFu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+  return ((unsigned long long)u << 32) | (unsigned)(~idx);
+}
+__global__ __launch_bounds__(1024) void argsort_desc_kernel(const float* v, int n, long long* order) {
+  __shared__ __attribute__((aligned(16))) unsigned long long tile[4][256];
+  __shared__ int part[4][256];
+  const int e = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int i = blockIdx.x * 256 + e;
+  const unsigned long long ki = i < n ? sort_key(v[i], i) : 0ull;
   int rank = 0;
-  for (int j0 = 0; j0 < n; j0 += 256) {
-    int j = j0 + threadIdx.x;
-    tile[threadIdx.x] = j < n ? v[j] : 0.f;
+  const int ntiles = (n + 255) / 256;
+  for (int t0 = 0; t0 < ntiles; t0 += 4) {
+    const int j = (t0 + q) * 256 + e;
+    tile[q][e] = j < n ? sort_key(v[j], j) : 0ull;    // key 0 sorts after everything (never counted)
     __syncthreads();
-    int m = n - j0 < 256 ? n - j0 : 256;
-    for (int k = 0; k < m; ++k) {
-      float vj = tile[k];
-      int jj = j0 + k;
-      bool nan_j = vj != vj;
-      bool before = nan_i ? (!nan_j || jj < i) : (!nan_j && (vj > vi || (vj == vi && jj < i)));
-      rank += before ? 1 : 0;
+#pragma unroll 8
+    for (int k = 0; k < 256; k += 2) {
+      const ulonglong2 kk = *(const ulonglong2*)&tile[q][k];
+      rank += (kk.x > ki) + (kk.y > ki);
     }
     __syncthreads();
   }
-  if (i < n) order[rank] = i;
+  part[q][e] = rank;
+  __syncthreads();
+  if (q == 0 && i < n) order[part[0][e] + part[1][e] + part[2][e] + part[3][e]] = i;
 }
 hipError_t launch_argsort_desc(const float* v, int n, long long* order, hipStream_t st) {
-  hipLaunchKernelGGL(argsort_desc_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v, n, order);
+  hipLaunchKernelGGL(argsort_desc_kernel, dim3((n + 255) / 256), dim3(1024), 0, st, v, n, order);
   return hipGetLastError();
 }
 
+// torch.argmax per group (max_by_values_in_batch, diffusion.py:51-62): the first maximum; NaN counts as the largest value
+// (the first NaN of a group wins), as torch.argmax does.
 __global__ __launch_bounds__(64) void group_argmax_kernel(const float* v, int per, long long* best) {
   const int gidx = blockIdx.x, lane = threadIdx.x;
-  float bv = -INFINITY;
+  float bv = 0.f;
   int bi = 0x7fffffff;
+  // a sorts before b: NaN before numbers, larger before smaller, lower index on ties
+  auto better = [](float xv, int xi, float yv, int yi) {
+    if (yi == 0x7fffffff) return xi != 0x7fffffff;
+    if (xi == 0x7fffffff) return false;
+    const bool xn = xv != xv, yn = yv != yv;
+    if (xn || yn) return xn && (!yn || xi < yi);
+    return xv > yv || (xv == yv && xi < yi);
+  };
   for (int i = lane; i < per; i += 64) {
-    float x = v[(size_t)gidx * per + i];
-    if (x > bv || (x == bv && i < bi) || bi == 0x7fffffff) { bv = x; bi = i; }
+    const float x = v[(size_t)gidx * per + i];
+    if (better(x, i, bv, bi)) { bv = x; bi = i; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(bv, o, 64);
-    int oi = __shfl_xor(bi, o, 64);
-    if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
   }
   if (lane == 0) best[gidx] = (long long)gidx * per + bi;
 }

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(1024) void gnb_kernel(GnbP p) {
 }
 hipError_t launch_gnb(const GnbP& p, int nblk, hipStream_t st) {
   const size_t lds = (size_t)(3 * p.C + (p.ptime ? p.T * p.C : 0)) * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;          // trebi_trainer_create refuses such shapes (train_lds_limits)
   hipLaunchKernelGGL(gnb_kernel, dim3(nblk), dim3(1024), lds, st, p);
   return hipGetLastError();
 }
@@ -486,6 +487,8 @@ hipError_t train_init_device() {
     e = hipFuncSetAttribute((const void*)wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)time_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)gnb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
 }
 

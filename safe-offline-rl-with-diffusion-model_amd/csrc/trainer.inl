@@ -305,6 +305,20 @@ extern "C" int trebi_trainer_create(trebi_ctx* ctx, const trebi_train_desc* desc
       return e;
   }
   trebi_net* net = tr->net;
+  // The backward keeps per-timestep tables in LDS: gnb_kernel (3 + T) x C floats for a block with a time bias,
+  // time_mlp_bwd_kernel T x 14 dim + 4 dim^2 floats.  Refuse here what does not fit (the reference's default
+  // n_timesteps = 1000 does not; its configs use 20), not at the first accumulate with a bare launch error.
+  {
+    const size_t T = (size_t)desc->n_timesteps, dim = (size_t)nd.dim;
+    size_t gnb_max = 0;
+    for (auto& t : net->tops)
+      if (t.kind == 1) gnb_max = std::max(gnb_max, (size_t)(3 + (t.time_blk >= 0 ? T : 0)) * t.C * sizeof(float));
+    const size_t tmlp = (T * 14 * dim + 4 * dim * dim) * sizeof(float);
+    if (gnb_max > 160 * 1024 || tmlp > 160 * 1024)
+      return fail(TREBI_UNSUPPORTED_CONFIG, "n_timesteps = %d with dim = %d: the training backward keeps per-timestep tables in "
+                  "LDS (GroupNorm backward %zu bytes, time-MLP backward %zu bytes; limit 163840)", desc->n_timesteps, nd.dim,
+                  gnb_max, tmlp);
+  }
   for (size_t c = 0; c < net->allocs.size(); ++c) {
     int* mp = nullptr;
     HIPCHK(hipMalloc((void**)&mp, net->alloc_bytes[c]));
@@ -525,6 +539,8 @@ extern "C" int trebi_trainer_accumulate(trebi_trainer* tr, const float* x_start,
   const std::vector<Tile>& tf = itf->second;
   const std::vector<Tile>& tbw = tr->tiles_bwd[tkey];
 
+  if (poison_on())
+    if (int e = poison_ws(tr->ws, net->ws_floats(B), st)) return e;
   // ---- q_sample + conditioning, forward, loss (diffusion.py:240-254) ----
   HIPCHK(launch_qsample(sp, x_start, noise, (const long long*)tsteps, tr->sa, tr->sb, tr->xnoisy, B, st));
   Binding b;

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -70,6 +71,7 @@ struct trebi_ctx {
 static __device__ __align__(256) unsigned char g_static_scratch[TREBI_STATIC_SCRATCH_BYTES];
 constexpr int MAX_DEVICES = 64;
 static void* g_scratch_ptr[MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;
 
 // ------------------------------------------------------------------------------------
 // plan data structures
@@ -978,7 +980,11 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
   const int KK = (op.ntaps * op.Cin_p + op.Cin2_p) / 16;
   ConvP q{};
   q.Lout = op.Lout; q.stride = op.stride; q.ntaps = op.ntaps; q.Cin_p = op.Cin_p;
-  q.x2 = op.src2.id != NONE ? (const float*)1 : nullptr;
+  // stand-in sources for the LDS carve (conv_make_geo asks conv_vec_ok): workspace buffers are float4-addressable, a
+  // caller tensor (row stride = transition_dim) is taken not to be -- the carve then never assumes the W5-only late staging
+  q.x = (const float*)16; q.ldx = op.src.id >= 0 ? 4 : 1; q.Cin = op.Cin;
+  q.x2 = op.src2.id != NONE ? (const float*)16 : nullptr;
+  q.ldx2 = op.src2.id >= 0 ? 4 : 1; q.Cin2 = op.Cin2;
   q.Cin2_p = op.Cin2_p; q.gn = op.gn; q.gch = op.gn ? op.gnw.gch : 1;
   q.Lin = op.Lin; q.pro = op.pro ? 1 : 0; q.tbias = op.tbias;
   q.res = op.res.id != NONE ? (const float*)1 : nullptr;
@@ -1048,7 +1054,7 @@ Tile choose_tile(const Op& op, int B, int nz = 1, bool bf = false) {
           // (the channel-block-major loop of conv_w5_ok has neither the chain nor the branches; what it pays for is its
           // weight stream, so the eight-tile one-column waves, with half the requests per MFMA, come out ~10 % ahead of
           // the four-tile ones, which run as fast as the tap-major loop did: measured per layer at 8192 candidates)
-          const bool w5 = pm && conv_w5_ok(q, t);
+          const bool w5 = pm && conv_w5_ok(q, t) && conv_vec_ok(q);
           const double pmk = pm ? (NI == 1 ? (w5 ? (MI == 8 ? 0.92 : 1.05) : 1.25) : 1.05) : 1.0;
           const double mfma = 32.0 * 4 * MI * NI * chunk * frac * pmk;     // cycles of one wave's matrix work
           const double simd = mfma * std::max(1.0, occ * NG * KS / 4.0);   // waves of a SIMD share its matrix core
@@ -1147,6 +1153,21 @@ struct GemmProfile {
   }
 };
 
+// Debug aid: TREBI_POISON=1 fills every caller workspace with NaN before each network pass, so a
+// kernel that reads an activation no earlier kernel of the pass wrote shows up as NaN in the result instead of silently
+// re-using the previous call's data (tests/test_gpu_paths.py runs the golden loops that way).  Read once per process.
+static bool poison_on() {
+  static const bool on = getenv("TREBI_POISON") && atoi(getenv("TREBI_POISON")) != 0;
+  return on;
+}
+static int poison_ws(float* ws, size_t floats, hipStream_t st) {
+  for (size_t o = 0; o < floats; o += (size_t)1 << 30) {
+    const size_t n = std::min(floats - o, (size_t)1 << 30);
+    HIPCHK(launch_fill_f(ws + o, (int)n, std::nanf(""), st));
+  }
+  return 0;
+}
+
 // Run a list of ops for one net, or for two structurally identical nets in the same launches.
 int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, const trebi_net* n1,
             const Binding* b1, const std::vector<Op>* ops1, int B, bool want_grad, hipStream_t st,
@@ -1154,6 +1175,11 @@ int run_ops(const std::vector<Op>& ops, const trebi_net* n0, const Binding& b0, 
   Resolver r0{n0, n0->offsets(B), b0, B};
   Resolver r1{n1 ? n1 : n0, n1 ? n1->offsets(B) : std::vector<size_t>(), n1 ? *b1 : b0, B};
   int nz = n1 ? 2 : 1;
+  if (poison_on() && &ops == &n0->fwd) {           // once per pass: the backward reads what the forward saved
+    if (int e = poison_ws(b0.ws, n0->ws_floats(B), st)) return e;
+    if (n1)
+      if (int e = poison_ws(b1->ws, n1->ws_floats(B), st)) return e;
+  }
   for (size_t i = 0; i < ops.size(); ++i) {
     const Op& op = ops[i];
 #ifdef TREBI_STAMPS
@@ -1667,10 +1693,13 @@ extern "C" int trebi_ctx_create(int device, trebi_ctx** out) {
                 prop.gcnArchName);
   HIPCHK(conv_init_device());
   HIPCHK(chain_init_device());
-  if (device < MAX_DEVICES && !g_scratch_ptr[device]) {
-    void* p = nullptr;
-    HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch)));
-    g_scratch_ptr[device] = p;
+  if (device < MAX_DEVICES) {                      // once per device, that device current; contexts may be created concurrently
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+      void* p = nullptr;
+      HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch)));
+      g_scratch_ptr[device] = p;
+    }
   }
   *out = new trebi_ctx{device};
   return 0;
@@ -2165,6 +2194,13 @@ static int enqueue_loop(trebi_sampler* s, const float* noise, const float* const
   }
   for (int i = T - 1; i >= 0; --i) {
     const long long* t = s->tbuf + (size_t)i * B;
+    if (poison_on()) {                             // every pass of this step starts from NaN-filled workspaces
+      if (int e = poison_ws(s->ws_u, s->unet->ws_floats(B), st)) return e;
+      if (s->reward)
+        if (int e = poison_ws(s->ws_r, s->reward->ws_floats(B), st)) return e;
+      if (s->cost)
+        if (int e = poison_ws(s->ws_c, s->cost->ws_floats(B), st)) return e;
+    }
     if (d.kind >= 1) {
       const bool stopped = i < d.step.t_stopgrad;          // gradient is zeroed: x cannot change (functions.py:116)
       const bool dead = stopped && i != 0;                 // ... and y is only returned from the last step
@@ -2200,7 +2236,11 @@ extern "C" int trebi_sampler_bind(trebi_sampler* s, const float* noise, const fl
   const void* key[12] = {noise, thr, x, values, costs, chain};
   for (int k = 0; k < s->d.step.n_cond; ++k) key[6 + k] = cond[k];
   if (s->d.use_graph && (!s->exec || memcmp(key, s->key, sizeof key) != 0)) {
-    if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+    if (s->exec) {
+      HIPCHK(hipDeviceSynchronize());              // a launch of the old executable graph may still be in flight
+      (void)hipGraphExecDestroy(s->exec);
+      s->exec = nullptr;
+    }
     hipStream_t cap;
     HIPCHK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;

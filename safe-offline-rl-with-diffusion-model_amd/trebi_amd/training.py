@@ -255,18 +255,22 @@ class Trainer:
             step = self.step
             losses = self.train_step(batches)
             total.extend(losses)
-            if step % self.save_freq == 0:
-                self.save(step // self.label_freq * self.label_freq)
+            if step % self.save_freq == 0:                  # the reference saves BEFORE `self.step += 1` (training.py:124-138)
+                self.save(step // self.label_freq * self.label_freq, step=step)
             if step % self.log_freq == 0:
                 l = losses[-1].tolist()
                 print(f'{step}: {l[0] / self.gradient_accumulate_every:8.4f} | a0_loss: {l[1]:8.4f}', flush=True)
         print('mean loss : ', float(torch.stack(total)[:, 0].mean()))
 
     # ---- checkpoints in the reference's format (training.py:141-166) ----
-    def save(self, epoch):
-        os.makedirs(self.logdir, exist_ok=True)
-        data = {'step': self.step, 'model': self.model.state_dict(), 'ema': self.ema_model.state_dict()}
+    def save(self, epoch, step=None):
+        """`step`: the value stored under 'step' (default self.step).  Data-parallel: every rank holds the same state, rank 0
+        writes the file."""
         path = os.path.join(self.logdir, f'state_{epoch}.pt')
+        if self.distributed and dist.get_rank(self.group) != 0:
+            return path
+        os.makedirs(self.logdir, exist_ok=True)
+        data = {'step': self.step if step is None else step, 'model': self.model.state_dict(), 'ema': self.ema_model.state_dict()}
         torch.save({k: ({n: v.detach().cpu().clone() for n, v in d.items()} if isinstance(d, dict) else d)
                     for k, d in data.items()}, path)
         return path

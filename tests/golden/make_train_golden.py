@@ -89,5 +89,68 @@ def main():
         print('wrote', name, os.path.getsize(os.path.join(HERE, f'{name}.npz')) // 1024, 'KiB')
 
 
+# ---- a third fixture that PINS the optimiser and the EMA rule ----------------------------
+# With ema_decay 0.995, lr 2e-4 and two steps the only true EMA update moves an element by ~1e-6: below any tolerance a
+# float32 test can state, so a no-op EMA kernel would have passed.  Here: 4 optimiser steps, ema_decay 0.9, lr 1e-3,
+# step_start_ema = 1 (step 0 copies, steps 1-3 average), and per step the sampled GRADIENT elements as well, so that the
+# tests can tell the elements whose Adam update is determined by the gradient from those driven by rounding noise (the
+# conv biases in front of a GroupNorm have a mathematically zero gradient).  64 sampled elements per tensor, float32.
+PIN = dict(name='train_ema_pin', obs=3, act=1, mults=(1, 4, 8), H=32, B=3, steps=4, lr=1e-3, ema_decay=0.9, nsample=64)
+
+
+def sample(v, n):
+    v = np.asarray(v, np.float32).reshape(-1)
+    return v[np.linspace(0, v.size - 1, min(v.size, n)).astype(np.int64)].copy()
+
+
+def main_pin():
+    helpers, temporal, diffusion, guides, functions = load_reference()
+    torch.set_num_threads(8)
+    cfg = PIN
+    name, obs, act, H, B, ns = cfg['name'], cfg['obs'], cfg['act'], cfg['H'], cfg['B'], cfg['nsample']
+    D = obs + act
+    unet = temporal.TemporalUnet(H, D, 0, dim=DIM, dim_mults=cfg['mults'])
+    sd = synth.synth_state_dict(spec.unet_param_shapes(H, D, DIM, cfg['mults']), SEED_W)
+    unet.load_state_dict(to_torch_sd(sd), strict=True)
+    diff = diffusion.GaussianDiffusion(unet, H, obs, act, n_timesteps=T, loss_type='l2', clip_denoised=False,
+                                       predict_epsilon=False, action_weight=ACTION_WEIGHT, loss_discount=1, loss_weights=None)
+    names = [k for k, _ in unet.named_parameters()]
+    opt = torch.optim.Adam(diff.parameters(), lr=cfg['lr'])           # betas (0.9, 0.999), eps 1e-8: training.py:79
+    ema = {k: p.detach().clone() for k, p in unet.named_parameters()}
+    out = dict(obs=obs, act=act, H=H, B=B, T=T, dim=DIM, mults=np.array(cfg['mults']), seed_w=SEED_W, lr=cfg['lr'],
+               accum=ACCUM, ema_decay=cfg['ema_decay'], action_weight=ACTION_WEIGHT, steps=cfg['steps'], nsample=ns,
+               names=np.array(names))
+    for step in range(cfg['steps']):
+        for i in range(ACCUM):
+            tag = f's{step}m{i}'
+            x0 = torch.from_numpy(synth.synth_normal(SEED_D, f'{name}.{tag}.x', (B, H, D)))
+            c0 = torch.from_numpy(synth.synth_normal(SEED_D, f'{name}.{tag}.c', (B, obs)))
+            x0[:, 0, act:] = c0
+            noise = torch.from_numpy(synth.synth_normal(SEED_D, f'{name}.{tag}.n', (1, B, H, D)))
+            t = torch.from_numpy(np.random.default_rng([SEED_D, step, i]).integers(0, T, size=B))
+            out[f'{tag}_x'], out[f'{tag}_c'], out[f'{tag}_n'], out[f'{tag}_t'] = (
+                x0.numpy().copy(), c0.numpy().copy(), noise[0].numpy().copy(), t.numpy().copy())
+            with inject_noise(noise) as inj:
+                loss, info = diff.p_losses(x0, {0: c0}, t)
+                assert inj.i == 1
+            out[f'{tag}_loss'] = float(loss)
+            (loss / ACCUM).backward()
+        for k, p in unet.named_parameters():
+            out[f'g{step}.{k}'] = sample(p.grad.numpy(), ns)          # the accumulated gradient the optimiser sees
+        opt.step()
+        opt.zero_grad()
+        for k, p in unet.named_parameters():                          # training.py:94-98 with step_start_ema = 1, every step
+            ema[k] = p.detach().clone() if step < 1 else ema[k] * cfg['ema_decay'] + (1 - cfg['ema_decay']) * p.detach()
+        for k, p in unet.named_parameters():
+            out[f'p{step}.{k}'] = sample(p.detach().numpy(), ns)
+            out[f'ema{step}.{k}'] = sample(ema[k].numpy(), ns)
+        print(name, 'step', step, 'losses', [out[f's{step}m{i}_loss'] for i in range(ACCUM)])
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    print('wrote', name, os.path.getsize(os.path.join(HERE, f'{name}.npz')) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'pin':
+        main_pin()
+    else:
+        main()

@@ -22,6 +22,9 @@ def _mk(cls, sd, *a, **k):
 @pytest.mark.parametrize('name,total', [('hopper', 512), ('walker148', 8192), ('halfcheetah', 130),
                                         # position-major tiles (>= 512 candidates) on the other shapes, ragged tails
                                         ('halfcheetah', 601), ('halfcheetah_h4', 1030), ('pendulum_h128', 515),
+                                        # H = 4 where the W5 / late-staging tiles are eligible (>= 4096): its first block's
+                                        # second source is the caller's x with a row stride of 23 floats
+                                        ('halfcheetah_h4', 4100),
                                         ('pendulum', 4100),
                                         # default chain policy: two candidates per workgroup (161-448) and four (449-512),
                                         # with a last workgroup that is not full

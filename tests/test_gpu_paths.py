@@ -19,6 +19,9 @@ CONFIGS = {
     'split_k_chains_only': {'TREBI_CHAIN_DIRECT': '0'},
     'wide_chains_two_per_workgroup': {'TREBI_CHAIN_MAXN': '256', 'TREBI_CHAIN_S': '2'},
     'direct_single_layers': {'TREBI_DIRECT_SINGLE': '1', 'TREBI_CHAIN': '0'},
+    # debug aid of SURVEY.md section 5: workspaces NaN-filled before every pass -- nothing may read what it did not write
+    'poisoned_workspaces': {'TREBI_POISON': '1'},
+    'poisoned_workspaces_no_chains': {'TREBI_POISON': '1', 'TREBI_CHAIN': '0'},
 }
 
 

@@ -142,6 +142,41 @@ def test_selection_kernels():
     assert torch.equal(bx.reshape(-1).long(), exp) and torch.equal(bv, v[exp])
 
 
+def test_selection_at_the_global_size_with_ties_and_nan():
+    """The selection every rank runs on the all-gathered scores of configs[3] (65536 candidates): descending argsort with
+    massive ties (infeasible scores are quantised by the -1e8 shift, functions.py:129) and NaN, which torch.argsort
+    (sort_by_values, diffusion.py:44-49) orders BEFORE every number; torch.argmax (max_by_values_in_batch) returns the first
+    NaN of a group.  Bit-exact against torch on the host (stable sort: the kernel breaks ties by index)."""
+    import time
+    from trebi_amd.diffusion import argsort_descending, max_by_values_in_batch
+    rng = np.random.default_rng(5)
+    n = 65536
+    v = rng.standard_normal(n).astype(np.float32)
+    v[rng.integers(0, n, n // 3)] = np.float32(-1e8)          # ties
+    v[rng.integers(0, n, n // 8)] = 0.25
+    v[rng.integers(0, n, 37)] = np.nan
+    tv = torch.from_numpy(v)
+    want = torch.argsort(tv, descending=True, stable=True)
+    dv = tv.cuda()
+    got = argsort_descending(dv)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        argsort_descending(dv)
+    torch.cuda.synchronize()
+    print(f'argsort_desc_kernel at n = {n}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms')
+    for rows, per in ((64, 1024), (7, 333)):
+        g = v[:rows * per].copy()
+        g[3 * per + 5] = np.nan
+        g[3 * per + 9] = np.nan
+        gt = torch.from_numpy(g)
+        x = torch.arange(rows * per, device='cuda', dtype=torch.float32).reshape(-1, 1, 1)
+        bx, bv, bc = max_by_values_in_batch(x, gt.cuda(), gt.cuda(), rows)
+        exp = gt.reshape(rows, per).argmax(1) + torch.arange(rows) * per
+        assert torch.equal(bx.reshape(-1).long().cpu(), exp)
+
+
 def test_sharded_planner_single_rank_equals_loop(setup):
     """world_size 1: ShardedPlanner.plan == p_sample_loop's best candidate; and slicing the batch in two
     (a fake 2-rank world on one device) reproduces the unsharded result (candidates are independent)."""

@@ -136,6 +136,82 @@ def test_accumulation_adam_and_ema_follow_the_reference(fx):
     assert torch.equal(tr.model.model(x, None, t), fresh(x, None, t))
 
 
+def test_optimizer_and_ema_pin():
+    """Adam and the EMA rule of the HIP step (adam_ema_kernel) over 4 optimiser steps against the reference, with a
+    decay (0.9) and a learning rate (1e-3) large enough that a wrong or absent EMA update, a misplaced eps or a wrong bias
+    correction is far outside the bars (tests/golden/train_ema_pin.npz; bars in _common.check_optimizer_pin)."""
+    from _common import check_optimizer_pin
+    from trebi_amd.training import Trainer
+    fx = np.load(os.path.join(GOLDEN, 'train_ema_pin.npz'))
+    diff, sd = _model(fx)
+    tr = Trainer(diff, train_batch_size=8, train_lr=float(fx['lr']), gradient_accumulate_every=int(fx['accum']),
+                 ema_decay=float(fx['ema_decay']), step_start_ema=1, update_ema_every=1)
+    ps, es = [], []
+    for step in range(int(fx['steps'])):
+        losses = tr.train_step([_batch(fx, step, i) for i in range(int(fx['accum']))])
+        torch.cuda.synchronize()
+        for i, l in enumerate(losses):
+            want = float(fx[f's{step}m{i}_loss'])
+            assert abs(float(l[0]) - want) <= 1e-4 * abs(want), (step, i)
+        ps.append({k: v.detach().cpu().numpy().copy() for k, v in tr.model.model.state_dict().items()})
+        es.append({k: v.detach().cpu().numpy().copy() for k, v in tr.ema_model.model.state_dict().items()})
+    print('worst Adam deviation / lr %.2e, worst EMA ratio deviation %.2e (%d / %d elements)' % check_optimizer_pin(fx, ps, es))
+
+
+def test_trainer_refuses_time_tables_that_do_not_fit_the_lds():
+    """The backward keeps per-timestep tables in LDS (gnb_kernel, time_mlp_bwd_kernel): GaussianDiffusion's default
+    n_timesteps = 1000 must be refused at trebi_trainer_create with a message, not fail at the first launch."""
+    from diffuser.models import TemporalUnet, GaussianDiffusion
+    unet = TemporalUnet(32, 23, 0, dim=32, dim_mults=(1, 2, 4, 8))
+    diff = GaussianDiffusion(unet, 32, 17, 6, n_timesteps=1000, loss_type='l2', clip_denoised=False, predict_epsilon=False).cuda()
+    with pytest.raises(RuntimeError, match='per-timestep tables'):
+        diff.train_engine(max_batch=8)
+
+
+def test_training_step_at_horizon_4():
+    """The reference's in-repo halfcheetah shape (H = 4, dim_mults (1,4,8), config/locomotion.py:295-314) through the training
+    kernels: gradients of a small batch against the numpy oracle, and the 4096-sample batch through linearity (a batch of
+    copies has the same loss and gradient) -- the size at which the chooser turns to position-major / W5 tiles."""
+    import trebi_oracle as O
+    import trebi_train_oracle as TO
+    from diffuser.models import TemporalUnet, GaussianDiffusion
+    H, obs, act, T, dim, mults, B = 4, 17, 6, 20, 32, (1, 4, 8), 8
+    D = obs + act
+    sd = synth.synth_state_dict(spec.unet_param_shapes(H, D, dim, mults), 77)
+    unet = TemporalUnet(H, D, 0, dim=dim, dim_mults=mults)
+    unet.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    diff = GaussianDiffusion(unet, H, obs, act, n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False,
+                             action_weight=10.0).cuda()
+    eng = diff.train_engine(max_batch=4096)
+    x = synth.synth_normal(6, 'h4.x', (B, H, D))
+    c = synth.synth_normal(6, 'h4.c', (B, obs))
+    x[:, 0, act:] = c
+    n = synth.synth_normal(6, 'h4.n', (B, H, D))
+    t = np.random.default_rng(4).integers(0, T, size=B)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    loss, _ = diff.p_losses(cu(x), {0: cu(c)}, cu(t), noise=cu(n))
+    torch.cuda.synchronize()
+    ol, _, og = TO.p_losses(TO.TrainableUnet(sd, H, D, dim, mults), x, {0: c}, t, n, TO.loss_weights(H, D, act, 10.0), act,
+                            O.make_schedule(T))
+    assert abs(float(loss) - ol) <= 1e-4 * abs(ol)
+    got = _grads(eng)
+    for k, ref in og.items():
+        err = np.abs(got[k] - ref.reshape(got[k].shape)).max() / max(np.abs(ref).max(), 1e-12)
+        assert err < 1e-3, (k, err)
+    g1 = eng.grads.clone()
+    eng.grads.zero_()
+    idx = torch.arange(4096, device='cuda') % B
+    lossN, _ = diff.p_losses(cu(x)[idx], {0: cu(c)[idx]}, cu(t)[idx], noise=cu(n)[idx])
+    torch.cuda.synchronize()
+    assert abs(float(lossN) - float(loss)) <= 1e-5 * abs(float(loss))
+    off = 0
+    for k, shape in eng.unet._shapes.items():
+        m = int(np.prod(shape))
+        a, b = g1[off:off + m], eng.grads[off:off + m]
+        assert float((a - b).abs().max() / a.abs().max().clamp_min(1e-12)) < 1e-3, k
+        off += m
+
+
 @pytest.mark.parametrize('B', [1, 37])
 def test_ragged_batches_vs_oracle(B):
     """Batch sizes that fill no tile and no K-split evenly, per-sample timesteps; full tensors vs the oracle."""

@@ -100,3 +100,28 @@ def test_adam_and_ema_updates(replay, which):
             tot += d.size
             assert d.max() <= 2.05 * lr * (step + 1), k            # never worse than a flipped sign
         assert bad <= 0.01 * tot, (which, step, bad, tot)
+
+
+def test_optimizer_and_ema_pin():
+    """The oracle's Adam and EMA against the reference over 4 steps with a decay and a learning rate large enough to see
+    (tests/golden/train_ema_pin.npz; bars in _common.check_optimizer_pin)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from _common import check_optimizer_pin
+    fx = np.load(os.path.join(GOLDEN, 'train_ema_pin.npz'))
+    obs, act, H, T = int(fx['obs']), int(fx['act']), int(fx['H']), int(fx['T'])
+    mults = tuple(int(m) for m in fx['mults'])
+    sd = synth.synth_state_dict(spec.unet_param_shapes(H, obs + act, int(fx['dim']), mults), int(fx['seed_w']))
+    ema = {k: v.copy() for k, v in sd.items()}
+    opt = TO.Adam(lr=float(fx['lr']))
+    ps, es = [], []
+    for step in range(int(fx['steps'])):
+        batches = [(fx[f's{step}m{i}_x'], {0: fx[f's{step}m{i}_c']}, fx[f's{step}m{i}_t'], fx[f's{step}m{i}_n'])
+                   for i in range(int(fx['accum']))]
+        losses, _ = TO.train_step(sd, ema, opt, batches, H, obs, act, T, step, action_weight=float(fx['action_weight']),
+                                  ema_decay=float(fx['ema_decay']), step_start_ema=1, update_ema_every=1,
+                                  dim=int(fx['dim']), dim_mults=mults)
+        for i, (loss, _a0) in enumerate(losses):
+            assert abs(loss - float(fx[f's{step}m{i}_loss'])) <= 2e-5 * abs(loss), (step, i)
+        ps.append({k: v.copy() for k, v in sd.items()})
+        es.append({k: v.copy() for k, v in ema.items()})
+    print('worst Adam deviation / lr %.2e, worst EMA ratio deviation %.2e (%d / %d elements)' % check_optimizer_pin(fx, ps, es))
