@@ -49,15 +49,18 @@ def test_nets_golden_bf16x3(name):
     assert not torch.equal(f32(x, None, t), unet(x, None, t))
 
 
-def test_large_batch_chain_bf16x3():
-    """The production route: 600 copies of the golden candidates (>= 512: no resident chains, bf16x3 on the single-layer
-    launches, position-major tiles) must reproduce the golden 20-step constrained plan in every copy."""
+@pytest.mark.parametrize('name,total', [('halfcheetah', 600), ('walker148', 8192)])
+def test_large_batch_chain_bf16x3(name, total):
+    """The production route: copies of the golden candidates (>= 512: no resident chains, bf16x3 on the single-layer
+    launches, position-major tiles) must reproduce the golden 20-step constrained plan in every copy.  600 candidates, and
+    the per-GPU size of configs[3] (walker2d shapes, UNet (1,4,8), 8192 candidates): the size bench.py prints its bf16x3
+    figure at, where the tile chooser picks other instantiations than at 600."""
     from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
     from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
-    fx = load_fixture('halfcheetah')
+    fx = load_fixture(name)
     sd_u, sd_r, sd_c, um, vm = fixture_weights(fx)
     H, obs, act, dim, T = int(fx['H']), int(fx['obs']), int(fx['act']), int(fx['dim']), int(fx['T'])
-    D, Bg, total = obs + act, int(fx['B']), 600
+    D, Bg = obs + act, int(fx['B'])
     kw = dict(n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False)
     mk = lambda cls, sd, m: _mk(cls, sd, H, D, 0, dim=dim, dim_mults=m).set_precision('bf16x3')     # default threshold (512)
     diff = GaussianDiffusion(mk(TemporalUnet, sd_u, um), H, obs, act, **kw).cuda()
@@ -109,3 +112,42 @@ def test_training_gradients_bf16x3():
         assert err < GRAD_TOL, (k, err)
         off += n
     print('worst bf16x3 training-gradient error vs oracle:', worst)
+
+
+def test_training_full_batch_bf16x3_through_linearity():
+    """bench.py prints a bf16x3 training figure at micro-batches of 4096: at that size the mode engages by itself (default
+    threshold 512) on other tiles than at batch 4.  A batch of 4096 copies of the golden micro-batch has the golden loss
+    and gradient (the loss is a mean); gradients within 5e-4 of each tensor's largest element against the FP32 gradient of
+    the golden micro-batch, which test_gpu_train.py holds to the reference."""
+    from diffuser.models import TemporalUnet, GaussianDiffusion
+    fx = np.load(os.path.join(GOLDEN, 'train_halfcheetah.npz'))
+    obs, act, H, T = int(fx['obs']), int(fx['act']), int(fx['H']), int(fx['T'])
+    mults = tuple(int(m) for m in fx['mults'])
+    D, total = obs + act, 4096
+    sd = synth.synth_state_dict(spec.unet_param_shapes(H, D, int(fx['dim']), mults), int(fx['seed_w']))
+    unet = TemporalUnet(H, D, 0, dim=int(fx['dim']), dim_mults=mults)
+    unet.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    diff = GaussianDiffusion(unet, H, obs, act, n_timesteps=T, loss_type='l2', clip_denoised=False, predict_epsilon=False,
+                             action_weight=float(fx['action_weight'])).cuda()
+    eng = diff.train_engine(max_batch=total)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x, c, t, n = cu(fx['s0m0_x']), cu(fx['s0m0_c']), cu(fx['s0m0_t']), cu(fx['s0m0_n'])
+    loss1, _ = diff.p_losses(x, {0: c}, t, noise=n)                     # fp32, golden micro-batch
+    g1 = eng.grads.clone()
+    eng.grads.zero_()
+    eng.set_precision('bf16x3')                                         # default threshold: engages at 4096
+    idx = torch.arange(total, device='cuda') % x.shape[0]
+    lossN, _ = diff.p_losses(x[idx], {0: c[idx]}, t[idx], noise=n[idx])
+    torch.cuda.synchronize()
+    assert abs(float(lossN) - float(loss1)) <= 1e-3 * abs(float(loss1))
+    assert abs(float(lossN) - float(fx['s0m0_loss'])) <= 1e-3 * abs(float(fx['s0m0_loss']))
+    off, worst = 0, 0.0
+    for k, shape in unet._shapes.items():
+        m = int(np.prod(shape))
+        a, b = g1[off:off + m], eng.grads[off:off + m]
+        err = float((a - b).abs().max() / a.abs().max().clamp_min(1e-12))
+        worst = max(worst, err)
+        assert err < GRAD_TOL, (k, err)
+        off += m
+    assert not torch.equal(g1, eng.grads)                               # the mode really was on
+    print('worst bf16x3 training-gradient error at 4096 samples vs the fp32 gradient:', worst)
