@@ -173,6 +173,71 @@ __device__ __forceinline__ f32x4 ld4(const float* sp, int left, bool vec) {
   return vec ? load4<true>(sp, left) : load4<false>(sp, left);
 }
 
+// The value head as a chain stage (RStage::head): Linear(fc + dim -> hd) with the time columns folded into the table row,
+// Mish, Linear(hd -> 1), and the seed of the backward dL/dv = W1^T (w2 * mish'(h)).  One wave per candidate; W1 is staged
+// in LDS once per workgroup (row stride fc + 4 floats: rows for the forward, columns for the backward, both conflict-free).
+// Arithmetic and summation order are head_kernel's (kernels.hip), so the two routes agree bit for bit.
+__device__ __forceinline__ void head_stage(const DV& dv, const DV& dvn, const bool has_next, float* smem, const int tid,
+                                        const int b0, f32x4 (&wreg)[3][WREG], const float* ptab, const int parN) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fc = DP(Cin), hd = DP(N), S = DG(S), B = DP(B), ldw = fc + 4;
+  const int nvs = (B - b0 < S) ? B - b0 : S;
+  float* w1s = smem + DS(oHead);
+  float* dhs = w1s + hd * ldw;
+  float* vs = dhs + S * hd;
+  const float* w1 = DP(w);
+  const int fc4 = fc >> 2;
+#pragma clang loop unroll(disable)
+  for (int e = tid; e < hd * fc4; e += 512) {
+    const int row = e / fc4, c4 = e - row * fc4;
+    *(f32x4*)&w1s[row * ldw + 4 * c4] = gld4(w1 + (size_t)row * fc + 4 * c4);
+  }
+  const bool srcRes = DS(srcRes) != 0;
+  if (!srcRes)
+    for (int e = tid; e < nvs * fc; e += 512) vs[e] = gld(DP(x) + (size_t)b0 * fc + e);
+  const bool dstRes = DS(dstRes) != 0;
+  float* dreg = smem + DS(oD);
+  const int RbD = DS(RbD), ldD = DS(ldD);
+  if (dstRes) {                                          // zero halo rows of the resident destination
+    const int ld4n = ldD >> 2, tot = S * 4 * ld4n;
+    for (int idx = tid; idx < tot; idx += 512) {
+      const int h = idx / ld4n, c4 = idx - h * ld4n;
+      const int s = h >> 2, k = h & 3;
+      *(f32x4*)&dreg[(s * RbD + (k < 2 ? k : DS(Ld) + k)) * ldD + 4 * c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  lds_barrier();
+  if (wave < nvs) {
+    const int s = wave;
+    const float* v = srcRes ? smem + DS(oSrc) + (s * DS(Rb) + 2) * DG(ldA) : vs + s * fc;
+    float ysum = 0.f;
+    for (int j = lane; j < hd; j += 64) {
+      float h = ptab[3 * parN + j];                      // W1[:, fc:] @ temb(t) + b1
+      const float* wr = w1s + j * ldw;
+#pragma clang loop unroll(disable)
+      for (int i = 0; i < fc; ++i) h = fmaf(wr[i], v[i], h);
+      const float w2 = ptab[parN + j];
+      ysum += w2 * mish_f(h);
+      dhs[s * hd + j] = w2 * mish_grad_f(h);
+    }
+    ysum = wave_sum(ysum);
+    if (lane == 0) gst(DP(out) + b0 + s, ysum + ptab[4 * parN]);
+    float* dvg = DP(save_y);
+    if (dstRes || dvg) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's dh is in LDS (one wave per candidate)
+      for (int i = lane; i < fc; i += 64) {
+        float a = 0.f;
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < hd; ++j) a = fmaf(w1s[j * ldw + i], dhs[s * hd + j], a);
+        if (dstRes) dreg[(s * RbD + 2) * ldD + i] = a;
+        if (dvg) gst(dvg + (size_t)(b0 + s) * fc + i, a);
+      }
+    }
+  }
+  // (behind the head's own arithmetic: with 96 weight registers live across it the kernel spilled)
+  if (has_next) wprefetch<true>(winfo_of(dvn), wave, lane, wreg);
+}
+
 template <int MI, int NI, bool DIRECT>
 __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool has_next, float* smem, const int tid,
                                          const int b0, int t_uniform, const long long* tptr,
@@ -913,7 +978,9 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
 
 // DIRECT: every stage is a direct stage (one kernel per stage kind keeps each kernel's register
 // footprint within two waves per SIMD without spilling).
-template <bool DIRECT>
+// HEAD: the chain contains the value head as a stage (head_stage).  An instantiation of its own: with the head's code in the
+// kernel every direct chain ran ~6 % slower (the same stage code, other register allocation and waits).
+template <bool DIRECT, bool HEAD = false>
 __global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __restrict__ stages, int nstages,
                                                              int t_uniform, const long long* tptr,
                                                              const float* __restrict__ cpar, int parN, int parT, int oTab) {
@@ -948,7 +1015,9 @@ __global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __res
     if (DS(drain)) drain_barrier();
 #define RC_ARGS dv, dvn, has_next, smem, tid, b0, t_uniform, tptr, wreg, skey, i, tabdst + i * 5 * parN, parN, tabv, tabdst, \
                 (DIRECT && i == 0) ? tabn4 : 0
-    if (DIRECT) {
+    if (HEAD && DS(head)) {
+      head_stage(dv, dvn, has_next, smem, tid, b0, wreg, tabdst + i * 5 * parN, parN);
+    } else if (DIRECT) {
       rc_stage<1, 1, true>(RC_ARGS);
     } else {
       switch (DS(MI) * 4 + DS(NI)) {
@@ -996,18 +1065,27 @@ hipError_t chain_init_device() {
   hipError_t e = hipFuncSetAttribute((const void*)resident_chain_kernel<true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)resident_chain_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)resident_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
   return e;
 }
 
 hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, int ny, size_t lds_bytes,
-                        int t_uniform, const long long* t, const float* cpar, int parN, int parT, int oTab, hipStream_t st) {
+                        int t_uniform, const long long* t, const float* cpar, int parN, int parT, int oTab, int has_head,
+                        hipStream_t st) {
+  if (has_head && !direct) return hipErrorInvalidValue;
   if (direct) {
     // the parameter table is indexed by the launch's (uniform) timestep and must fit the registers that carry it
     if (!cpar || t_uniform < 0 || parN < 16 || (parN & 15) || nstages * 5 * parN > 4 * 512 * TABV) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(resident_chain_kernel<true>, dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,
-                       nstages, t_uniform, t, cpar, parN, parT, oTab);
+    if (has_head)
+      hipLaunchKernelGGL((resident_chain_kernel<true, true>), dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,
+                         nstages, t_uniform, t, cpar, parN, parT, oTab);
+    else
+      hipLaunchKernelGGL(resident_chain_kernel<true>, dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,
+                         nstages, t_uniform, t, cpar, parN, parT, oTab);
   } else
     hipLaunchKernelGGL(resident_chain_kernel<false>, dim3(nblocks, 1, nz), dim3(512), lds_bytes, st, dev_stages,
                        nstages, t_uniform, t, cpar, parN, parT, oTab);

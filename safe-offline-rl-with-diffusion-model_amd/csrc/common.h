@@ -98,6 +98,11 @@ struct RStage {
   unsigned mLd4;                   // magic multiplier of ldD / 4
   int proRes, oPro;                // backward stage whose incoming gradient is resident (read-only) at oPro
   int direct;                      // no split-K: a wave owns a 16-row x (16*NI)-column tile and finishes it in registers
+  // The value head (temporal.py:237-238) as a stage of a direct chain: p.x / the resident source = the flattened mid_down2
+  // output [fc = p.Cin], p.w = W1 [hd = p.N][fc], p.tbias = the head's time table, p.gamma = w2, p.bias2 = b2 (replicated), p.out = y [B],
+  // p.save_y = dL/dv [B, fc] (global copy, or null); the destination region takes dL/dv for the backward's first stage.
+  int head;
+  int oHead;                       // LDS scratch of the head stage: W1 [hd][fc + 4], dh [S][hd], v [S][fc]
 };
 
 struct Tile {
@@ -126,7 +131,8 @@ hipError_t chain_init_device();
 // cpar: per-column parameter table of a direct chain, [nz][parT][nstages][5][parN] floats (bias, gamma, beta, time-bias row,
 // bias2; defaults 0,1,0,0,0 past N), filled by launch_chain_params; oTab: float offset of its LDS copy.
 hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, int ny, size_t lds_bytes,
-                        int t_uniform, const long long* t, const float* cpar, int parN, int parT, int oTab, hipStream_t st);
+                        int t_uniform, const long long* t, const float* cpar, int parN, int parT, int oTab, int has_head,
+                        hipStream_t st);
 hipError_t launch_chain_params(const ConvP& p, float* dst /* + ((z*T + t)*nstages + stage)*5*parN */, int parN, int T,
                                size_t t_stride, hipStream_t st);
 

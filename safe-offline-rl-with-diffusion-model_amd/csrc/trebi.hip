@@ -183,6 +183,7 @@ struct trebi_net {
   const float* head_tb = nullptr;
   const float* head_w2 = nullptr;
   float head_b2 = 0.f;
+  const float* head_b2_dev = nullptr;              // [hd] copies of head_b2 (a row of the chains' parameter table)
   int fc = 0, hd = 0;
   double flops_fwd = 0, flops_bwd = 0;
   // bf16x3 operand mode (trebi_net_set_precision): copies of the packed weights, engaged from bf_min_b candidates up
@@ -923,11 +924,15 @@ void build_value(Builder& B, const ArchPlan& a) {
   net->head_tb = B.time_table("final_block.0.weight", "final_block.0.bias", hd, fc + dim, fc, false);
   net->head_w2 = B.upload(B.host("final_block.2.weight", hd), hd);
   net->head_b2 = B.host("final_block.2.bias", 1)[0];
+  net->head_b2_dev = B.upload(std::vector<float>((size_t)hd, net->head_b2));
   Op head;
   head.kind = 1;
   head.name = "final_block";
   head.v_buf = cur.id;
   head.dv_buf = net->new_buf(fc);
+  // (as a chain stage -- plan_chain -- it is a layer from [1, fc] to [1, fc]: the flattened mid_down2 output in, dL/dv out)
+  head.Lin = head.Lout = 1; head.Cin = head.Cin_p = fc; head.N = head.Npad = fc;
+  head.src = cur; head.dst = {head.dv_buf, fc, 0};
   head.flops = 2.0 * hd * fc + 2.0 * hd;
   net->fwd.push_back(head);
 
@@ -1246,7 +1251,7 @@ struct PlanStep {
   int chain_off = 0, chain_n = 0, nblocks = 0, chain_direct = 0, ny = 1;
   size_t chain_lds = 0;
   size_t par_off = 0;              // direct chains: float offset of the parameter table in the sampler's table arena
-  int parN = 0, parT = 0, oTab = 0;
+  int parN = 0, parT = 0, oTab = 0, has_head = 0;
   double flops = 0;                // algorithmic, whole batch, all nets of the launch
   std::string name;
 };
@@ -1327,15 +1332,28 @@ bool chain_tile(const Op& op, int S, int max_n, Tile* out, bool* direct) {
 
 // Try to fold ops [i, ...) into one resident-chain launch; returns the number of ops folded (0: none).
 size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>& o1, size_t i, const Resolver& r0,
-                  const Resolver* r1, int B, int S, int max_n, std::vector<RStage>& tab, ParTab& par, Plan& plan) {
+                  const Resolver* r1, int B, int S, int max_n, bool want_grad, std::vector<RStage>& tab, ParTab& par,
+                  Plan& plan) {
   const int nz = r1 ? 2 : 1;
   std::vector<Tile> tiles;
   std::vector<char> directs;
   size_t j = i;
   static const size_t max_len = getenv("TREBI_CHAIN_MAXLEN") ? (size_t)atoi(getenv("TREBI_CHAIN_MAXLEN")) : 1000;
+  // The value head as a stage of the chain it follows (chain.hip head_stage): one launch and one boundary fewer per value
+  // pass, and the tail of the forward runs into the head of the backward.  Built, parity-tested (test_gpu_paths.py), and
+  // OFF by default: at 64 candidates the planning call takes 18.92 ms with it and 18.71 ms without (profiles/r03_negative_
+  // results.md) -- the kernel instantiation that carries the head's code runs its ordinary stages slower than the plain one.
+  static const bool head_in_chain = getenv("TREBI_CHAIN_HEAD") && atoi(getenv("TREBI_CHAIN_HEAD")) != 0;
   while (j < o0.size() && j - i < max_len) {
     Tile tl;
     bool direct = false;
+    if (o0[j]->kind == 1) {          // the value head: a stage of a direct chain (never its first: the first stage brings the table in)
+      if (!head_in_chain || directs.empty() || !directs[0] || S > 8 || o0[j]->Cin % 4 || r0.net->hd > 64) break;
+      tiles.push_back(Tile{1, 1, 0, 0, S});
+      directs.push_back(1);
+      ++j;
+      continue;
+    }
     if (!chain_tile(*o0[j], S, max_n, &tl, &direct)) break;
     if (!directs.empty() && (bool)directs[0] != direct) break;      // one stage kind per launch
     tiles.push_back(tl);
@@ -1348,6 +1366,7 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
   };
   auto key_of = [](const BufRef& r, int C) { return Key{r.id, r.coloff, C}; };
   auto reads = [&](const Op& op, const Key& k) {      // op reads exactly this logical tensor
+    if (op.kind == 1) return key_of(op.src, op.Cin) == k;
     if (op.kind != 0) return false;
     return key_of(op.src, op.Cin) == k || (op.src2.id != NONE && key_of(op.src2, op.Cin2) == k) ||
            (op.res.id != NONE && key_of(op.res, op.N) == k);
@@ -1363,20 +1382,39 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
     struct Live { Key k; int region; size_t last; int L; };
     std::vector<Live> live;
     constexpr int MAXREG = 4;
-    size_t regsz = 0, slabsz = 0, slab2sz = 0, restsz = 0, redsz = 0, red2sz = 0, colsz = 0, tbsz = 0;
+    size_t regsz = 0, slabsz = 0, slab2sz = 0, restsz = 0, redsz = 0, red2sz = 0, colsz = 0, tbsz = 0, headsz = 0;
     int nreg = 0;
     std::vector<int> written;                          // workspace ids stored to global by earlier stages
     double fl = 0;
     for (size_t k = 0; k < n; ++k) {
       const Op& op = *o0[i + k];
       RStage& st = run[k];
-      st.p[0] = r0.conv(op);
-      if (r1) st.p[1] = r1->conv(*o1[i + k]);
       const Tile& tl = tiles[k];
       st.MI = tl.MI; st.NI = tl.NI;
       st.direct = directs[k];
+      if (op.kind == 1) {              // the value head (RStage::head, chain.hip head_stage)
+        auto head_p = [&](const Resolver& r, const Op& o) {
+          const HeadP h = r.head(o, want_grad);
+          ConvP p{};
+          p.x = h.v; p.ldx = h.fc; p.Cin = p.Cin_p = h.fc; p.Lin = p.Lout = 1; p.stride = 1; p.ntaps = 1;
+          p.w = h.w1; p.tbias = h.tb; p.gn = 1; p.gch = 1; p.gamma = h.w2; p.N = p.Npad = h.hd;
+          p.bias2 = r.net->head_b2_dev;                  // b2 replicated over hd columns: the table's last row
+          p.out = h.y; p.save_y = h.dv; p.T = h.T; p.t_uniform = -1; p.B = B;
+          return p;
+        };
+        st.p[0] = head_p(r0, op);
+        if (r1) st.p[1] = head_p(*r1, *o1[i + k]);
+        st.head = 1;
+        st.vec = 1;
+        st.g = ConvGeo{};
+        st.g.S = S; st.g.ldA = op.Cin + 8;
+        headsz = std::max(headsz, (size_t)r0.net->hd * (op.Cin + 4) + (size_t)S * r0.net->hd + (size_t)S * op.Cin);
+      } else {
+      st.p[0] = r0.conv(op);
+      if (r1) st.p[1] = r1->conv(*o1[i + k]);
       st.vec = conv_vec_ok(st.p[0]) && (!r1 || conv_vec_ok(st.p[1]));
       st.g = conv_make_geo(st.p[0], tl);
+      }
       const ConvGeo& G = st.g;
       auto find_live = [&](const Key& kk) -> Live* {
         for (auto& l : live) if (l.k == kk) return &l;
@@ -1445,7 +1483,9 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
       } else if (last > 0) {
         need_global = true;
       }
-      if (!need_global) { st.p[0].out = nullptr; st.p[1].out = nullptr; }
+      if (op.kind == 1) {               // the head's `out` is y; its tensor destination (dL/dv) is save_y
+        if (!need_global) { st.p[0].save_y = nullptr; st.p[1].save_y = nullptr; }
+      } else if (!need_global) { st.p[0].out = nullptr; st.p[1].out = nullptr; }
       if (need_global && op.dst.id >= 0) written.push_back(op.dst.id);
       for (int id : {op.save_y, op.save_g, op.save_st}) if (id >= 0) written.push_back(id);
       // remember region indices of the sources (offsets are assigned once the carve is known)
@@ -1471,7 +1511,7 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
     regsz = r4(regsz);
     const size_t oSlab = nreg * regsz, oSlab2 = oSlab + r4(slabsz), oRest = oSlab2 + r4(slab2sz),
                  oRed = oRest + r4(restsz), oRed2 = oRed + r4(redsz), oCol = oRed2 + r4(red2sz),
-                 oTb = oCol + r4(colsz), total = oTb + r4(tbsz);
+                 oTb = oCol + r4(colsz), oHead = oTb + r4(tbsz), total = oHead + r4(headsz);
     // direct chains: LDS copy of the per-column parameter table behind everything else
     int parN = 16;
     for (size_t k = 0; k < n; ++k) parN = std::max(parN, o0[i + k]->Npad);
@@ -1484,7 +1524,7 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
       st.o2 = st.x2Res ? (int)(st.o2 * regsz) : (int)oSlab2;
       st.oR = st.resRes ? (int)(st.oR * regsz) : (int)oRest;
       st.oD = st.dstRes ? (int)(st.oD * regsz) : 0;
-      st.oRed = (int)oRed; st.oRed2 = (int)oRed2; st.oColp = (int)oCol; st.oTb = (int)oTb;
+      st.oRed = (int)oRed; st.oRed2 = (int)oRed2; st.oColp = (int)oCol; st.oTb = (int)oTb; st.oHead = (int)oHead;
     }
     PlanStep ps;
     ps.kind = 2; ps.nz = nz;
@@ -1494,6 +1534,7 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
     if (directs[0]) {
       ps.parN = parN; ps.parT = run[0].p[0].T; ps.oTab = (int)total;
       ps.par_off = par.add(run, nz, parN, ps.parT);
+      for (auto& st : run) ps.has_head |= st.head;
     }
     ps.name = std::string(directs[0] ? "direct " : "") + "chain[" + std::to_string(n) + "] S" + std::to_string(S) + " " + o0[i]->name + " .. " + o0[j - 1]->name;
     tab.insert(tab.end(), run.begin(), run.end());
@@ -1578,7 +1619,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
   size_t i = 0;
   while (i < o0.size()) {
     const Op& op = *o0[i];
-    if (op.kind == 1) {
+    if (op.kind == 1) {                // (a direct chain takes the head as a stage when it follows one of its stages: plan_chain)
       PlanStep st;
       st.kind = 1; st.nz = nz;
       st.H.p[0] = r0.head(op, want_grad);
@@ -1589,7 +1630,7 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
       continue;
     }
     if (chain_S > 0) {
-      size_t n = plan_chain(o0, o1, i, r0, r1, B, chain_S, chain_max_n, tab, par, plan);
+      size_t n = plan_chain(o0, o1, i, r0, r1, B, chain_S, chain_max_n, want_grad, tab, par, plan);
       if (n) { i += n; continue; }
     }
     if (plan_direct_single(op, r1 ? o1[i] : nullptr, r0, r1, B, tab, par, plan)) { ++i; continue; }
@@ -1646,7 +1687,7 @@ int exec_plan(const Plan& plan, const RStage* dev_tab, const float* dev_par, int
     }
     if (ps.kind == 2) {
       HIPCHK(launch_chain(dev_tab + ps.chain_off, ps.chain_n, ps.chain_direct, ps.nz, ps.nblocks, ps.ny, ps.chain_lds, t_uniform, tptr,
-                          dev_par + ps.par_off, ps.parN, ps.parT, ps.oTab, st));
+                          dev_par + ps.par_off, ps.parN, ps.parT, ps.oTab, ps.has_head, st));
     } else {
       ConvLaunch L = ps.L;
       for (int z = 0; z < ps.nz; ++z) { L.p[z].t = tptr; L.p[z].t_uniform = t_uniform; }
