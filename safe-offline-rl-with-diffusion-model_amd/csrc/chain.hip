@@ -238,7 +238,11 @@ __device__ __forceinline__ void head_stage(const DV& dv, const DV& dvn, const bo
   if (has_next) wprefetch<true>(winfo_of(dvn), wave, lane, wreg);
 }
 
-template <int MI, int NI, bool DIRECT>
+// FEAT: what the chain's stages may need, decided per launch on the host so that a chain's kernel carries no code for the
+// rest (bit 0: a GroupNorm-backward prologue -- value-net backward chains; bit 1: saved GroupNorm operands -- value-net
+// forward chains; TemporalUnet chains need neither).  Measured: the less code the kernel carries, the faster the SAME stage
+// code runs (register allocation, waits).
+template <int MI, int NI, bool DIRECT, int FEAT = 3>
 __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool has_next, float* smem, const int tid,
                                          const int b0, int t_uniform, const long long* tptr,
                                          f32x4 (&wreg)[3][WREG], int skey, int sidx, const float* ptab, const int parN,
@@ -258,7 +262,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
   PIN(S); PIN(NG); PIN(KS); PIN(nthr); PIN(TM); PIN(TN); PIN(TNp); PIN(R); PIN(ldA); PIN(ld2);
   PIN(cbpt); PIN(KK1); PIN(KK); PIN(chunk); PIN(nv); PIN(fh); PIN(Rb); PIN(a0); PIN(Rb2); PIN(h2);
   CSTAMP(7);
-  const bool has2 = DP(Cin2_p) != 0, haspro = DP(pro) != 0, hasres = DP(res) != nullptr || DS(resRes),
+  const bool has2 = DP(Cin2_p) != 0, haspro = (FEAT & 1) && DP(pro) != 0, hasres = DP(res) != nullptr || DS(resRes),
              hastb = DP(tbias) != nullptr, hasgn = DP(gn) != 0;
   const bool vec = DS(vec) != 0;
   const bool active = tid < nthr;
@@ -787,8 +791,8 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
     CSTAMP(12);
     if (active) {
       const FastDiv dG(DG(gch4), DG(mGch4));
-      float* sy = DP(save_y);
-      float* sg = DP(save_g);
+      float* sy = (FEAT & 2) ? DP(save_y) : nullptr;
+      float* sg = (FEAT & 2) ? DP(save_g) : nullptr;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int col = cols[ni];
@@ -819,7 +823,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
           const int sw = sq[q], lo = loq[q];
           float val = v[ni][q];
           if (hasgn) {
-            if (DP(save_stats) && lo == 0 && (col & (gch - 1)) == 0) {
+            if ((FEAT & 2) && DP(save_stats) && lo == 0 && (col & (gch - 1)) == 0) {
               float* o = DP(save_stats) + ((unsigned)(b0 + sw) * GN_GROUPS + dG.div(col >> 2)) * 2;
               gst(o, mean);
               gst(o + 1, rstd);
@@ -980,7 +984,7 @@ __device__ __forceinline__ void rc_stage(const DV& dv, const DV& dvn, const bool
 // footprint within two waves per SIMD without spilling).
 // HEAD: the chain contains the value head as a stage (head_stage).  An instantiation of its own: with the head's code in the
 // kernel every direct chain ran ~6 % slower (the same stage code, other register allocation and waits).
-template <bool DIRECT, bool HEAD = false>
+template <bool DIRECT, bool HEAD = false, int FEAT = 3>
 __global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __restrict__ stages, int nstages,
                                                              int t_uniform, const long long* tptr,
                                                              const float* __restrict__ cpar, int parN, int parT, int oTab) {
@@ -1018,7 +1022,7 @@ __global__ __launch_bounds__(512) void resident_chain_kernel(const RStage* __res
     if (HEAD && DS(head)) {
       head_stage(dv, dvn, has_next, smem, tid, b0, wreg, tabdst + i * 5 * parN, parN);
     } else if (DIRECT) {
-      rc_stage<1, 1, true>(RC_ARGS);
+      rc_stage<1, 1, true, FEAT>(RC_ARGS);
     } else {
       switch (DS(MI) * 4 + DS(NI)) {
         case 1 * 4 + 1: rc_stage<1, 1, false>(RC_ARGS); break;
@@ -1068,6 +1072,15 @@ hipError_t chain_init_device() {
     e = hipFuncSetAttribute((const void*)resident_chain_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
   if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)resident_chain_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)resident_chain_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)resident_chain_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)resident_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
   return e;
@@ -1075,13 +1088,22 @@ hipError_t chain_init_device() {
 
 hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, int ny, size_t lds_bytes,
                         int t_uniform, const long long* t, const float* cpar, int parN, int parT, int oTab, int has_head,
-                        hipStream_t st) {
+                        int feat, hipStream_t st) {
   if (has_head && !direct) return hipErrorInvalidValue;
   if (direct) {
     // the parameter table is indexed by the launch's (uniform) timestep and must fit the registers that carry it
     if (!cpar || t_uniform < 0 || parN < 16 || (parN & 15) || nstages * 5 * parN > 4 * 512 * TABV) return hipErrorInvalidValue;
     if (has_head)
       hipLaunchKernelGGL((resident_chain_kernel<true, true>), dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,
+                         nstages, t_uniform, t, cpar, parN, parT, oTab);
+    else if (feat == 0)
+      hipLaunchKernelGGL((resident_chain_kernel<true, false, 0>), dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,
+                         nstages, t_uniform, t, cpar, parN, parT, oTab);
+    else if (feat == 1)
+      hipLaunchKernelGGL((resident_chain_kernel<true, false, 1>), dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,
+                         nstages, t_uniform, t, cpar, parN, parT, oTab);
+    else if (feat == 2)
+      hipLaunchKernelGGL((resident_chain_kernel<true, false, 2>), dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,
                          nstages, t_uniform, t, cpar, parN, parT, oTab);
     else
       hipLaunchKernelGGL(resident_chain_kernel<true>, dim3(nblocks, ny, nz), dim3(512), lds_bytes, st, dev_stages,

@@ -132,6 +132,7 @@ hipError_t chain_init_device();
 // bias2; defaults 0,1,0,0,0 past N), filled by launch_chain_params; oTab: float offset of its LDS copy.
 hipError_t launch_chain(const RStage* dev_stages, int nstages, int direct, int nz, int nblocks, int ny, size_t lds_bytes,
                         int t_uniform, const long long* t, const float* cpar, int parN, int parT, int oTab, int has_head,
+                        int feat /* bit 0: a stage has a GroupNorm-backward prologue, bit 1: a stage saves GroupNorm operands */,
                         hipStream_t st);
 hipError_t launch_chain_params(const ConvP& p, float* dst /* + ((z*T + t)*nstages + stage)*5*parN */, int parN, int T,
                                size_t t_stride, hipStream_t st);

@@ -112,24 +112,38 @@ __device__ __forceinline__ float stride_sum(float v, int g4) {
 __global__ __launch_bounds__(1024) void gnb_kernel(GnbP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int C = p.C, T = p.T;
-  float* colacc = sm;                       // [3][C]
-  float* ttab = sm + 3 * C;                 // [T][C]
-  const int nt = 3 * C + (p.ptime ? T * C : 0);
-  for (int i = threadIdx.x; i < nt; i += 1024) sm[i] = 0.f;
-  __syncthreads();
+  // No float atomics: sums are formed in a FIXED order, so the step is bit-reproducible.  A team always works on the same
+  // group (its instances are 64 x gridDim.x apart, a multiple of 8), so the gamma / beta / bias column sums accumulate in
+  // the team's registers over its sweeps and the eight teams of a group are combined once, in team order, through LDS; the
+  // time-bias rows, which depend on each candidate's timestep, are staged per sweep and added to the [T, C] table by one
+  // thread per column in team order (two barriers per sweep; a workgroup makes ~2 sweeps at a 4096 batch).
+  const int gch0 = p.gch;
+  float* ttab = sm;                         // [T][C]  (only with ptime)
+  float* stage = sm + (p.ptime ? T * C : 0);  // [64 teams][3][gch] column-sum parts, or [64][gch] time rows per sweep
+  int* tts = (int*)(stage + 64 * 3 * gch0);   // [64] timestep of each team's candidate
+  if (p.ptime)
+    for (int i = threadIdx.x; i < T * C; i += 1024) ttab[i] = 0.f;
   const int tl = threadIdx.x & 15, team = threadIdx.x >> 4;      // 64 teams of 16 lanes
   const int gch = p.gch, g4 = gch >> 2, L = p.L, cnt4 = L * g4;
   const float icnt = 1.f / (float)(cnt4 * 4);
   const int ninst = p.B * GN_GROUPS;
   const int c4 = tl & (g4 - 1);             // the float4 column of this lane inside the group (16 % g4 == 0)
-  for (int inst = blockIdx.x * 64 + team; inst < ninst; inst += gridDim.x * 64) {
-    const int b = inst >> 3, gi = inst & 7;
+  const int per_sweep = gridDim.x * 64;
+  const int first = blockIdx.x * 64;
+  const int nsweeps = first < ninst ? (ninst - first + per_sweep - 1) / per_sweep : 0;     // the same for every team
+  f32x4 acc_ga = {0.f, 0.f, 0.f, 0.f}, acc_be = acc_ga, acc_bi = acc_ga;
+  __syncthreads();
+  for (int it = 0; it < nsweeps; ++it) {
+    const int inst = first + team + it * per_sweep;
+    const bool valid = inst < ninst;
+    const int b = valid ? inst >> 3 : 0, gi = team & 7;
     const int c = gi * gch + 4 * c4;
+    f32x4 dga = {0.f, 0.f, 0.f, 0.f}, dbe = dga, dtb = dga, dbi = dga;
+    if (valid) {
     const float rstd = gld(p.stats + 2 * inst + 1);
     const f32x4 ga = gld4(p.gamma + c), be = gld4(p.beta + c);
     const size_t row0 = (size_t)b * L;
     float s1 = 0.f, s2 = 0.f;
-    f32x4 dga = {0.f, 0.f, 0.f, 0.f}, dbe = dga, dtb = dga, dbi = dga;
     if (cnt4 <= 32) {
       // at most two float4 per lane (every H = 32 shape): the gradient and xhat stay in registers for the second pass
       // instead of being read from HBM again (5 -> 3 streams of B x L x C floats; the kernel is HBM-bound)
@@ -209,29 +223,45 @@ __global__ __launch_bounds__(1024) void gnb_kernel(GnbP p) {
       dbi[q] = stride_sum(dbi[q], g4);
       dtb[q] = stride_sum(dtb[q], g4);
     }
-    if (tl < g4) {
-      long long tt = 0;
-      if (p.ptime) {
-        tt = gldll(p.t + b);
-        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+    }   // valid
+    acc_ga += dga; acc_be += dbe; acc_bi += dbi;                  // sweep order: fixed
+    if (p.ptime) {
+      if (tl < g4) *(f32x4*)&stage[team * gch + 4 * c4] = dtb;
+      if (tl == 0) {
+        long long tt = valid ? gldll(p.t + b) : 0;
+        tts[team] = (int)(tt < 0 ? 0 : (tt >= T ? T - 1 : tt));
       }
+      __syncthreads();
+      if ((int)threadIdx.x < 8 * gch) {                           // one thread per column, the group's eight teams in order
+        const int g = threadIdx.x / gch, cc = threadIdx.x - g * gch;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        atomicAdd(&colacc[c + q], dga[q]);
-        atomicAdd(&colacc[C + c + q], dbe[q]);
-        atomicAdd(&colacc[2 * C + c + q], dbi[q]);
-        if (p.ptime) atomicAdd(&ttab[(int)tt * C + c + q], dtb[q]);
+        for (int k = 0; k < 8; ++k) {
+          const int tm = g + 8 * k;
+          ttab[tts[tm] * C + g * gch + cc] += stage[tm * gch + cc];
+        }
       }
+      __syncthreads();
     }
   }
+  if (tl < g4) {
+    *(f32x4*)&stage[(team * 3 + 0) * gch + 4 * c4] = acc_ga;
+    *(f32x4*)&stage[(team * 3 + 1) * gch + 4 * c4] = acc_be;
+    *(f32x4*)&stage[(team * 3 + 2) * gch + 4 * c4] = acc_bi;
+  }
   __syncthreads();
-  for (int i = threadIdx.x; i < 3 * C; i += 1024) gst(p.pcol + (size_t)blockIdx.x * 3 * C + i, colacc[i]);
+  for (int i = threadIdx.x; i < 3 * C; i += 1024) {
+    const int kind = i / C, col = i - kind * C, g = col / gch, cc = col - g * gch;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += stage[((g + 8 * k) * 3 + kind) * gch + cc];
+    gst(p.pcol + (size_t)blockIdx.x * 3 * C + i, a);
+  }
   if (p.ptime)
     for (int i = threadIdx.x; i < T * C; i += 1024) gst(p.ptime + (size_t)blockIdx.x * T * C + i, ttab[i]);
 }
 hipError_t launch_gnb(const GnbP& p, int nblk, hipStream_t st) {
-  const size_t lds = (size_t)(3 * p.C + (p.ptime ? p.T * p.C : 0)) * sizeof(float);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;          // trebi_trainer_create refuses such shapes (train_lds_limits)
+  const size_t lds = ((size_t)(p.ptime ? p.T * p.C : 0) + (size_t)64 * 3 * p.gch + 64) * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;          // trebi_trainer_create refuses such shapes
   hipLaunchKernelGGL(gnb_kernel, dim3(nblk), dim3(1024), lds, st, p);
   return hipGetLastError();
 }

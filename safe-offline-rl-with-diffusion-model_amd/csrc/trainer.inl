@@ -305,14 +305,14 @@ extern "C" int trebi_trainer_create(trebi_ctx* ctx, const trebi_train_desc* desc
       return e;
   }
   trebi_net* net = tr->net;
-  // The backward keeps per-timestep tables in LDS: gnb_kernel (3 + T) x C floats for a block with a time bias,
+  // The backward keeps per-timestep tables in LDS: gnb_kernel T x C floats (+ 24 KB of staging) for a block with a time bias,
   // time_mlp_bwd_kernel T x 14 dim + 4 dim^2 floats.  Refuse here what does not fit (the reference's default
   // n_timesteps = 1000 does not; its configs use 20), not at the first accumulate with a bare launch error.
   {
     const size_t T = (size_t)desc->n_timesteps, dim = (size_t)nd.dim;
     size_t gnb_max = 0;
     for (auto& t : net->tops)
-      if (t.kind == 1) gnb_max = std::max(gnb_max, (size_t)(3 + (t.time_blk >= 0 ? T : 0)) * t.C * sizeof(float));
+      if (t.kind == 1) gnb_max = std::max(gnb_max, ((size_t)(t.time_blk >= 0 ? T : 0) * t.C + (size_t)64 * 3 * t.gn.gch + 64) * sizeof(float));
     const size_t tmlp = (T * 14 * dim + 4 * dim * dim) * sizeof(float);
     if (gnb_max > 160 * 1024 || tmlp > 160 * 1024)
       return fail(TREBI_UNSUPPORTED_CONFIG, "n_timesteps = %d with dim = %d: the training backward keeps per-timestep tables in "

@@ -1251,7 +1251,7 @@ struct PlanStep {
   int chain_off = 0, chain_n = 0, nblocks = 0, chain_direct = 0, ny = 1;
   size_t chain_lds = 0;
   size_t par_off = 0;              // direct chains: float offset of the parameter table in the sampler's table arena
-  int parN = 0, parT = 0, oTab = 0, has_head = 0;
+  int parN = 0, parT = 0, oTab = 0, has_head = 0, feat = 0;
   double flops = 0;                // algorithmic, whole batch, all nets of the launch
   std::string name;
 };
@@ -1340,10 +1340,11 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
   size_t j = i;
   static const size_t max_len = getenv("TREBI_CHAIN_MAXLEN") ? (size_t)atoi(getenv("TREBI_CHAIN_MAXLEN")) : 1000;
   // The value head as a stage of the chain it follows (chain.hip head_stage): one launch and one boundary fewer per value
-  // pass, and the tail of the forward runs into the head of the backward.  Built, parity-tested (test_gpu_paths.py), and
-  // OFF by default: at 64 candidates the planning call takes 18.92 ms with it and 18.71 ms without (profiles/r03_negative_
-  // results.md) -- the kernel instantiation that carries the head's code runs its ordinary stages slower than the plain one.
-  static const bool head_in_chain = getenv("TREBI_CHAIN_HEAD") && atoi(getenv("TREBI_CHAIN_HEAD")) != 0;
+  // pass (112 launches per planning call at the headline), and the tail of the forward runs into the head of the backward.
+  // Time-neutral at 64 candidates (five interleaved pairs of processes: median 18.75 ms with, 18.74 ms without; the
+  // process-to-process spread is +-0.3 ms): the kernel instantiation that carries the head's code runs its ordinary stages a
+  // little slower, which is what the saved boundaries return.  TREBI_CHAIN_HEAD=0: the head as a kernel of its own.
+  static const bool head_in_chain = !(getenv("TREBI_CHAIN_HEAD") && atoi(getenv("TREBI_CHAIN_HEAD")) == 0);
   while (j < o0.size() && j - i < max_len) {
     Tile tl;
     bool direct = false;
@@ -1534,7 +1535,10 @@ size_t plan_chain(const std::vector<const Op*>& o0, const std::vector<const Op*>
     if (directs[0]) {
       ps.parN = parN; ps.parT = run[0].p[0].T; ps.oTab = (int)total;
       ps.par_off = par.add(run, nz, parN, ps.parT);
-      for (auto& st : run) ps.has_head |= st.head;
+      for (auto& st : run) {
+        ps.has_head |= st.head;
+        if (!st.head) ps.feat |= (st.p[0].pro ? 1 : 0) | ((st.p[0].save_y || st.p[0].save_g || st.p[0].save_stats) ? 2 : 0);
+      }
     }
     ps.name = std::string(directs[0] ? "direct " : "") + "chain[" + std::to_string(n) + "] S" + std::to_string(S) + " " + o0[i]->name + " .. " + o0[j - 1]->name;
     tab.insert(tab.end(), run.begin(), run.end());
@@ -1600,6 +1604,7 @@ bool plan_direct_single(const Op& op, const Op* op1, const Resolver& r0, const R
   ps.chain_lds = (total + tabsz) * sizeof(float);
   ps.parN = parN; ps.parT = st.p[0].T; ps.oTab = (int)total;
   ps.par_off = par.add(std::vector<RStage>{st}, nz, parN, ps.parT);
+  ps.feat = (st.p[0].pro ? 1 : 0) | ((st.p[0].save_y || st.p[0].save_g || st.p[0].save_stats) ? 2 : 0);
   ps.flops = op.flops * B * nz;
   char tb[96];
   snprintf(tb, sizeof tb, " direct MS%d NG%d S%d grid %dx%d", MS, NG, S, ps.nblocks, ps.ny);
@@ -1687,7 +1692,7 @@ int exec_plan(const Plan& plan, const RStage* dev_tab, const float* dev_par, int
     }
     if (ps.kind == 2) {
       HIPCHK(launch_chain(dev_tab + ps.chain_off, ps.chain_n, ps.chain_direct, ps.nz, ps.nblocks, ps.ny, ps.chain_lds, t_uniform, tptr,
-                          dev_par + ps.par_off, ps.parN, ps.parT, ps.oTab, ps.has_head, st));
+                          dev_par + ps.par_off, ps.parN, ps.parT, ps.oTab, ps.has_head, ps.feat, st));
     } else {
       ConvLaunch L = ps.L;
       for (int z = 0; z < ps.nz; ++z) { L.p[z].t = tptr; L.p[z].t_uniform = t_uniform; }

@@ -20,7 +20,7 @@ CONFIGS = {
     'wide_chains_two_per_workgroup': {'TREBI_CHAIN_MAXN': '256', 'TREBI_CHAIN_S': '2'},
     'direct_single_layers': {'TREBI_DIRECT_SINGLE': '1', 'TREBI_CHAIN': '0'},
     # debug aid of SURVEY.md section 5: workspaces NaN-filled before every pass -- nothing may read what it did not write
-    'value_head_inside_the_chain': {'TREBI_CHAIN_HEAD': '1'},
+    'value_head_as_its_own_kernel': {'TREBI_CHAIN_HEAD': '0'},
     'poisoned_workspaces': {'TREBI_POISON': '1'},
     'poisoned_workspaces_no_chains': {'TREBI_POISON': '1', 'TREBI_CHAIN': '0'},
 }

@@ -18,8 +18,8 @@ for _ in range(3):
     run()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 20
+n = int(os.environ.get('CALLS', '40'))
 for _ in range(n):
     run()
 torch.cuda.synchronize()
-print(f"{os.environ.get('TREBI_LIB', 'product')}: {1e3 * (time.perf_counter() - t0) / n:.3f} ms per call", flush=True)
+print(f"{os.environ.get('LABEL') or os.environ.get('TREBI_LIB', 'product')}: {1e3 * (time.perf_counter() - t0) / n:.3f} ms per call", flush=True)
