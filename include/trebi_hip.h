@@ -303,6 +303,15 @@ int trebi_trainer_repack(trebi_trainer* tr, void* stream);
 int trebi_trainer_accumulate(trebi_trainer* tr, const float* x_start, const float* const* cond, const int64_t* t,
                              const float* noise, int B, float grad_scale, float* loss_out, void* stream);
 
+/* Gradient buckets for a data-parallel caller (no counterpart in training.py, which is single-GPU; the reduction
+ * itself is the caller's: torch.distributed / RCCL).  The backward finishes the gradients of the state_dict's tail --
+ * ups.*, mid_block1/2.*, final_conv.* = grads[trebi_trainer_bucket_split(), param_count) -- before it starts on the
+ * down path.  While an event is set (a hipEvent_t the caller owns; NULL clears it), every trebi_trainer_accumulate
+ * records it on its stream at that point, so a side stream can wait for it and all-reduce the tail slice while the
+ * down path's backward still runs; grads[0, split) are final when accumulate's last kernel is. */
+int64_t trebi_trainer_bucket_split(const trebi_trainer* tr);
+int trebi_trainer_set_bucket_event(trebi_trainer* tr, void* event);
+
 /* optimizer.step(); optimizer.zero_grad(); step_ema() (training.py:118-122, 94-98), then re-pack:
  * torch.optim.Adam with bias correction for the adam_step-th update (counting from 1);
  * ema_mode 0: EMA untouched, 1: ema = params (step < step_start_ema), 2: ema = ema*decay + (1-decay)*params. */

@@ -162,6 +162,7 @@ void build_unet_train_bwd(Builder& B, const ArchPlan& a) {
   const BufRef dm1{net->new_buf((size_t)rec.mid1.L * rec.mid1.cin), rec.mid1.cin, 0};
   rb_bwd(rec.mid1, dm2, &dm1);
   g = dm1;
+  net->top_split = (int)net->tops.size();
   // ---- down path in reverse; the skip gradients (right halves of dcat) join before downs.i.1 ----
   for (int i = n - 1; i >= 0; --i) {
     const RBInfo &r0 = rec.down0[i], &r1 = rec.down1[i];
@@ -244,10 +245,13 @@ struct trebi_trainer {
   float *lw = nullptr, *sa = nullptr, *sb = nullptr, *G = nullptr, *DT = nullptr;
   std::vector<float*> part;         // per backward step: its partial-sum table (kinds 1 and 3), or null
   std::vector<float*> part_time;    // per backward step: its per-timestep partial table (kind 1 with a time block)
+  // reduction jobs, those of the tail bucket (final_conv, up path, mid blocks: tops[0..top_split)) first
   RJob* dev_rjobs = nullptr;
-  int n_rjobs = 0, max_rjob_n = 0;
+  int n_rjobs = 0, n_rjobs_tail = 0, max_rjob_n = 0;
   TBJob* dev_tbjobs = nullptr;
-  int n_tb = 0;
+  int n_tb = 0, n_tb_tail = 0;
+  size_t split_off = 0;             // flat offset of the first tail-bucket parameter ("ups.0..." or "mid_block1...")
+  hipEvent_t bucket_event = nullptr;   // caller-owned: recorded when grads[split_off, total) are final
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *ema = nullptr;
   bool bound = false;
   std::map<int, std::vector<Tile>> tiles_fwd, tiles_bwd;
@@ -287,6 +291,16 @@ extern "C" int trebi_trainer_create(trebi_ctx* ctx, const trebi_train_desc* desc
   tr->ctx = ctx; tr->d = *desc; tr->maxB = max_batch;
   tr->pi = param_index(nd);
   const long P = tr->pi.total;
+  {                                  // the tail bucket is the state_dict's tail: ups.*, mid_block*, final_conv.* back to back
+    long first = P;
+    for (auto& sp : tr->pi.specs) {
+      const bool tail = sp.name.rfind("ups.", 0) == 0 || sp.name.rfind("mid_block", 0) == 0 || sp.name.rfind("final_conv", 0) == 0;
+      const long o = tr->pi.off[sp.name];
+      if (tail) first = std::min(first, o);
+      else if (o >= first) return fail(TREBI_HIP_ERROR, "internal: parameter order (%s after the up path)", sp.name.c_str());
+    }
+    tr->split_off = (size_t)first;
+  }
   if (P + 1 >= (1 << 24))
     return fail(TREBI_UNSUPPORTED_CONFIG, "%ld parameters: the index-coded pack needs fewer than 2^24", P);
   // ---- build the net from index-coded tensors, then turn every uploaded region into a gather map ----
@@ -384,6 +398,14 @@ extern "C" void trebi_trainer_destroy(trebi_trainer* tr) { delete tr; }
 
 extern "C" int64_t trebi_trainer_param_count(const trebi_trainer* tr) { return tr ? (int64_t)tr->pi.total : 0; }
 
+extern "C" int64_t trebi_trainer_bucket_split(const trebi_trainer* tr) { return tr ? (int64_t)tr->split_off : 0; }
+
+extern "C" int trebi_trainer_set_bucket_event(trebi_trainer* tr, void* event) {
+  if (!tr) return fail(TREBI_BAD_ARG, "null trainer");
+  tr->bucket_event = (hipEvent_t)event;
+  return 0;
+}
+
 extern "C" double trebi_trainer_flops(const trebi_trainer* tr, int backward) {
   if (!tr) return 0.0;
   return backward ? tr->net->flops_train_bwd : tr->net->flops_fwd;
@@ -447,16 +469,28 @@ extern "C" int trebi_trainer_bind(trebi_trainer* tr, float* params, float* grads
       tb[i].pad = 0;
     }
   }
-  for (size_t i = 0; i < net->tops.size(); ++i) {
-    const TOp& t = net->tops[i];
-    if (t.kind == 1) {
-      rj.push_back({tr->part[i], grads + t.off_gamma, NBLK, 3 * t.C, t.C, 0});
-      rj.push_back({tr->part[i] + t.C, grads + t.off_beta, NBLK, 3 * t.C, t.C, 0});
-      rj.push_back({tr->part[i] + 2 * t.C, grads + t.off_bias, NBLK, 3 * t.C, t.C, 0});
-      if (t.time_blk >= 0) rj.push_back({tr->part_time[i], Gof[t.time_blk], NBLK, T * t.C, T * t.C, 1});
-    } else if (t.kind == 3) {
-      rj.push_back({tr->part[i], grads + t.off_bias, NBLK, t.C, t.C, 0});
+  for (int pass = 0; pass < 2; ++pass) {             // pass 0: the tail bucket's steps, pass 1: the down path's
+    const size_t lo = pass ? (size_t)net->top_split : 0, hi = pass ? net->tops.size() : (size_t)net->top_split;
+    for (size_t i = lo; i < hi; ++i) {
+      const TOp& t = net->tops[i];
+      if (t.kind == 1) {
+        rj.push_back({tr->part[i], grads + t.off_gamma, NBLK, 3 * t.C, t.C, 0});
+        rj.push_back({tr->part[i] + t.C, grads + t.off_beta, NBLK, 3 * t.C, t.C, 0});
+        rj.push_back({tr->part[i] + 2 * t.C, grads + t.off_bias, NBLK, 3 * t.C, t.C, 0});
+        if (t.time_blk >= 0) rj.push_back({tr->part_time[i], Gof[t.time_blk], NBLK, T * t.C, T * t.C, 1});
+      } else if (t.kind == 3) {
+        rj.push_back({tr->part[i], grads + t.off_bias, NBLK, t.C, t.C, 0});
+      }
     }
+    if (!pass) tr->n_rjobs_tail = (int)rj.size();
+  }
+  {                                                  // time blocks in the same two groups (each keeps its own DT slot)
+    std::vector<TBJob> a, b;
+    for (size_t i = 0; i < tb.size(); ++i)
+      ((size_t)(tb[i].gW - grads) >= tr->split_off ? a : b).push_back(tb[i]);
+    tr->n_tb_tail = (int)a.size();
+    tb = a;
+    tb.insert(tb.end(), b.begin(), b.end());
   }
   tr->n_rjobs = (int)rj.size();
   tr->max_rjob_n = 0;
@@ -554,7 +588,19 @@ extern "C" int trebi_trainer_accumulate(trebi_trainer* tr, const float* x_start,
                      grad_scale * inv_count, tr->dout, loss_out, B, st));
 
   // ---- backward ----
+  // partial tables -> gradients and the per-block time Linears, per bucket: the tail bucket's parameters
+  // (final_conv, up path, mid blocks) are final once tops[0..top_split) have run, the rest at the end.
+  auto finish_bucket = [&](int which) -> int {
+    const int r0 = which ? tr->n_rjobs_tail : 0, r1 = which ? tr->n_rjobs : tr->n_rjobs_tail;
+    const int b0 = which ? tr->n_tb_tail : 0, b1 = which ? tr->n_tb : tr->n_tb_tail;
+    if (r1 > r0) HIPCHK(launch_reduce_jobs(tr->dev_rjobs + r0, r1 - r0, tr->max_rjob_n, st));
+    if (b1 > b0) HIPCHK(launch_time_block_bwd(tr->dev_tbjobs + b0, b1 - b0, net->tt_temb, dim, T, st));
+    if (!which && tr->bucket_event) HIPCHK(hipEventRecord(tr->bucket_event, st));
+    return 0;
+  };
   for (size_t i = 0; i < net->tops.size(); ++i) {
+    if ((int)i == net->top_split)
+      if (int e = finish_bucket(0)) return e;
     const TOp& t = net->tops[i];
     int ld = 0;
     switch (t.kind) {
@@ -618,8 +664,7 @@ extern "C" int trebi_trainer_accumulate(trebi_trainer* tr, const float* x_start,
     }
   }
   // ---- partial tables -> gradients; the time-embedding path (tables over the T timesteps) ----
-  HIPCHK(launch_reduce_jobs(tr->dev_rjobs, tr->n_rjobs, tr->max_rjob_n, st));
-  HIPCHK(launch_time_block_bwd(tr->dev_tbjobs, tr->n_tb, net->tt_temb, dim, T, st));
+  if (int e = finish_bucket(1)) return e;
   HIPCHK(launch_time_mlp_bwd(tr->DT, tr->n_tb, net->tt_e, net->tt_a1, net->tt_temb,
                              tr->params + tr->pi.off["time_mlp.3.weight"], dim, T,
                              tr->grads + tr->pi.off["time_mlp.1.weight"], tr->grads + tr->pi.off["time_mlp.1.bias"],

@@ -201,6 +201,7 @@ struct trebi_net {
   float *tt_e = nullptr, *tt_a1 = nullptr, *tt_temb = nullptr;
   UnetRec rec;
   std::vector<TOp> tops;
+  int top_split = 0;                // tops[0..top_split) finish the gradients of final_conv, the up path and the mid blocks
   std::vector<std::string> time_blocks;            // prefixes of the blocks with a time_mlp, in backward order of use
   int buf_dy = NONE, buf_colscratch = NONE;
   double flops_train_bwd = 0;

@@ -84,6 +84,8 @@ SIGNATURES = {
     'trebi_trainer_flops': (C.c_double, [_VP, C.c_int]),
     'trebi_trainer_bind': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, c_float_p, c_float_p, c_float_p]),
     'trebi_trainer_repack': (C.c_int, [_VP, _VP]),
+    'trebi_trainer_bucket_split': (C.c_int64, [_VP]),
+    'trebi_trainer_set_bucket_event': (C.c_int, [_VP, _VP]),
     'trebi_trainer_accumulate': (C.c_int, [_VP, _VP, C.POINTER(_VP), _VP, _VP, C.c_int, C.c_float, _VP, _VP]),
     'trebi_trainer_step': (C.c_int, [_VP, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float,
                                      _VP]),

@@ -96,6 +96,17 @@ class TrainEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @property
+    def bucket_split(self):
+        """grads[bucket_split:] (ups.*, mid_block*, final_conv.*) are final before the down path's backward runs."""
+        return int(_lib.lib().trebi_trainer_bucket_split(self.h))
+
+    def set_bucket_event(self, event):
+        """`event`: a torch.cuda.Event that has been recorded once (so that its handle exists), or None.  While set,
+        every accumulate() records it on its stream at the point where grads[bucket_split:] are final."""
+        handle = C.c_void_p(event.cuda_event) if event is not None else C.c_void_p()
+        _lib.check(_lib.lib().trebi_trainer_set_bucket_event(self.h, handle))
+
     def flops(self, backward=False):
         return _lib.lib().trebi_trainer_flops(self.h, 1 if backward else 0)
 
@@ -170,8 +181,10 @@ class Trainer:
     save / load -- rendering, wandb and cloud sync are outside the hot path and not built.
 
     Data-parallel: pass `group` (or have torch.distributed initialised): every rank accumulates over its own
-    micro-batches, then ONE all-reduce (sum) of the flat gradient per optimiser step; each micro-batch is scaled by
-    B_local / B_global so that the sum equals the gradient of the mean loss over the global batch.
+    micro-batches, then the flat gradient is all-reduced (sum) once per optimiser step, as two slices: the tail
+    bucket (up path, mid blocks, final conv: the first gradients the backward finishes) goes out on a side stream
+    while the last micro-batch's down-path backward still runs, the head bucket after it.  Each micro-batch is
+    scaled by B_local / B_global so that the sum equals the gradient of the mean loss over the global batch.
     `engine_factory` exists so that the distributed logic can be exercised on CPU ranks (gloo) without a GPU."""
 
     def __init__(self, diffusion_model, dataset=None, renderer=None, ema_decay=0.995, train_batch_size=32, train_lr=2e-5,
@@ -204,6 +217,7 @@ class Trainer:
                                                                 shuffle=True, pin_memory=True))
         self.step = 0
         self.adam_steps = 0
+        self._bucket_event = self._side = None
 
     def _world(self):
         return dist.get_world_size(self.group) if self.distributed else 1
@@ -215,6 +229,16 @@ class Trainer:
         dev = self.engine.device if hasattr(self.engine, 'device') else None
         world = self._world()
         losses = []
+        g = self.engine.grads
+        split = int(getattr(self.engine, 'bucket_split', 0)) if world > 1 else 0
+        split = split if 0 < split < g.numel() else 0
+        through_host = world > 1 and g.is_cuda and dist.get_backend(self.group) == 'gloo'
+        overlap = bool(split) and g.is_cuda and not through_host
+        if overlap and self._bucket_event is None:
+            self._bucket_event = torch.cuda.Event()
+            self._bucket_event.record(torch.cuda.current_stream(dev))      # creates the handle the library records
+            self._side = torch.cuda.Stream(dev)
+        tail_work = None
         for i, batch in enumerate(batches):
             x, cond = batch[0], batch[1]
             B = len(x)
@@ -225,15 +249,34 @@ class Trainer:
                 noise = torch.randn(tuple(x.shape), device=dev)
             Bg = global_batch_sizes[i] if global_batch_sizes is not None else B * world
             scale = (B / Bg if Bg else 0.0) / len(batches)                              # training.py:115
+            last = overlap and i == len(batches) - 1
+            if last:
+                if B:
+                    self.engine.set_bucket_event(self._bucket_event)
+                else:                                      # an empty shard enqueues nothing: the stream's tail is the point
+                    self._bucket_event.record(torch.cuda.current_stream(dev))
             losses.append(self.engine.accumulate(x, cond, t, noise, grad_scale=scale))
+            if last:
+                self.engine.set_bucket_event(None)
+                self._side.wait_event(self._bucket_event)
+                with torch.cuda.stream(self._side):        # the tail bucket leaves while the down path's backward runs
+                    tail_work = dist.all_reduce(g[split:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if world > 1:
-            g = self.engine.grads                                                       # the one collective per step
-            if g.is_cuda and dist.get_backend(self.group) == 'gloo':      # gloo (CPU rehearsals): through the host
-                gh = g.cpu()
-                dist.all_reduce(gh, op=dist.ReduceOp.SUM, group=self.group)
-                g.copy_(gh)
+            def reduce(v):
+                if through_host:                           # gloo (CPU rehearsals): through the host
+                    vh = v.cpu()
+                    dist.all_reduce(vh, op=dist.ReduceOp.SUM, group=self.group)
+                    v.copy_(vh)
+                else:
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            if tail_work is not None:
+                reduce(g[:split])
+                tail_work.wait()                           # the current stream waits for the side stream's collective
+            elif split:
+                reduce(g[split:])
+                reduce(g[:split])
             else:
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                reduce(g)
         self.adam_steps += 1
         ema_mode = 0
         if self.step % self.update_ema_every == 0:                                      # training.py:121-122, 94-98

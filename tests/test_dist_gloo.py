@@ -98,6 +98,8 @@ H_, OBS_, ACT_, T_, DIM_, MULTS_ = 8, 3, 1, 20, 32, (1, 2)
 
 
 class _OracleEngine:
+    bucket_split = 0                     # one collective; _TwoBucketEngine: the flat gradient leaves as two slices
+
     def __init__(self, diffusion, max_batch):
         sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'oracle'))
         import trebi_oracle as O
@@ -124,6 +126,10 @@ class _OracleEngine:
         self.grads.zero_()
 
 
+class _TwoBucketEngine(_OracleEngine):
+    bucket_split = 12345                 # any interior offset: Trainer must reduce [split:] and [:split], nothing twice
+
+
 def _train_batches(n):
     from trebi_amd import synth
     out = []
@@ -141,36 +147,38 @@ class _Model:
     n_timesteps = T_
 
 
-def _train(n, world, rank):
+def _train(n, world, rank, buckets=1):
     from trebi_amd.parallel import shard_bounds
     from trebi_amd.training import Trainer
     tr = Trainer(_Model(), train_batch_size=n, train_lr=2e-4, gradient_accumulate_every=2, step_start_ema=1,
-                 update_ema_every=1, engine_factory=_OracleEngine, distributed=world > 1)
+                 update_ema_every=1, engine_factory=_TwoBucketEngine if buckets == 2 else _OracleEngine,
+                 distributed=world > 1)
     lo, hi = shard_bounds(n, world, rank)
     batches = [(x[lo:hi], {0: c[lo:hi]}, t[lo:hi], nz[lo:hi]) for x, c, t, nz in _train_batches(n)]
     losses = tr.train_step(batches, global_batch_sizes=[n, n])
     return tr.engine.steps[0], [l.numpy() for l in losses], tr.step
 
 
-def _train_worker(rank, world, port, n, q):
+def _train_worker(rank, world, port, n, q, buckets):
     sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), 'safe-offline-rl-with-diffusion-model_amd')]
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    (adam_step, ema_mode, g), losses, step = _train(n, world, rank)
+    (adam_step, ema_mode, g), losses, step = _train(n, world, rank, buckets)
     q.put((rank, adam_step, ema_mode, g.numpy(), step))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n', [6, 7])
-def test_data_parallel_gradients_equal_single_rank(n):
-    """All-reduced gradients of 2 ranks (even and ragged shards) == the single-rank gradient of the whole batch."""
+@pytest.mark.parametrize('n,buckets', [(6, 1), (7, 1), (7, 2)])
+def test_data_parallel_gradients_equal_single_rank(n, buckets):
+    """All-reduced gradients of 2 ranks (even and ragged shards) == the single-rank gradient of the whole batch,
+    with the flat gradient reduced in one piece and as the two buckets the overlapped path uses."""
     (adam_step, ema_mode, ref), _, _ = _train(n, 1, 0)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 31500 + (os.getpid() + n) % 2000
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    port = 31500 + (os.getpid() + n + 7 * buckets) % 2000
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, n, q, buckets)) for r in range(2)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])

@@ -293,6 +293,77 @@ def test_gradients_are_bit_reproducible():
     assert float(outs[0].abs().max()) > 0
 
 
+def test_tail_bucket_is_final_at_its_event():
+    """trebi_trainer_set_bucket_event: what a side stream reads of grads[bucket_split:] after waiting for the event equals
+    the finished gradient bit for bit (1500 samples: the down path's backward is still running then), and setting the
+    event changes no gradient."""
+    fx = np.load(os.path.join(GOLDEN, 'train_halfcheetah.npz'))
+    diff, _ = _model(fx)
+    eng = diff.train_engine(max_batch=1500)
+    split = eng.bucket_split
+    names = eng.names
+    assert 0 < split < eng.grads.numel()
+    first_tail = [n for n, o in zip(names, np.cumsum([0] + [diff.model.state_dict()[k].numel() for k in names])[:-1])
+                  if o >= split][0]
+    assert first_tail.startswith('ups.0.'), first_tail
+    x, cond, t, noise = _batch(fx, 0, 0)
+    idx = torch.arange(1500, device='cuda') % x.shape[0]
+    tt = (t[idx] + torch.arange(1500, device='cuda')) % int(fx['T'])
+    eng.grads.zero_()
+    diff.p_losses(x[idx], {0: cond[0][idx]}, tt, noise=noise[idx])
+    torch.cuda.synchronize()
+    ref = eng.grads.clone()
+    ev = torch.cuda.Event()
+    ev.record()
+    side = torch.cuda.Stream()
+    eng.grads.zero_()
+    torch.cuda.synchronize()
+    eng.set_bucket_event(ev)
+    diff.p_losses(x[idx], {0: cond[0][idx]}, tt, noise=noise[idx])
+    eng.set_bucket_event(None)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        early = eng.grads[split:].clone()
+        head_then = eng.grads[:split].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.grads, ref)
+    assert torch.equal(early, ref[split:])
+    assert not torch.equal(head_then, ref[:split])      # the down path had not finished: the event is not just the end
+
+
+def test_two_bucket_all_reduce_on_the_device(tmp_path):
+    """Trainer.train_step's overlapped path (side stream, bucket event, async all-reduce of the tail slice through RCCL)
+    in a one-rank group made to look like two ranks: the sums are identities, so the step must equal the plain one."""
+    import torch.distributed as dist
+    from trebi_amd.training import Trainer
+    fx = np.load(os.path.join(GOLDEN, 'train_halfcheetah.npz'))
+    x, cond, t, noise = _batch(fx, 0, 0)
+    batches = [(x, cond, t, noise), (x.flip(0), {0: cond[0].flip(0)}, t.flip(0), noise.flip(0))]
+    B = x.shape[0]
+
+    def run(distributed):
+        diff, _ = _model(fx)
+        tr = Trainer(diff, train_batch_size=B, train_lr=1e-3, gradient_accumulate_every=2, step_start_ema=1,
+                     update_ema_every=1, distributed=distributed, results_folder=str(tmp_path))
+        if distributed:
+            tr._world = lambda: 2
+        for _ in range(2):
+            tr.train_step(batches, global_batch_sizes=[B, B])
+        torch.cuda.synchronize()
+        return tr.engine.params.clone(), tr.engine.ema.clone(), tr
+
+    p0, e0, _ = run(False)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29700 + os.getpid() % 200))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        p1, e1, tr = run(True)
+        assert tr._side is not None and tr._bucket_event is not None      # the overlapped path ran
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(p0, p1) and torch.equal(e0, e1)
+
+
 class _TinyDataset(torch.utils.data.Dataset):
     """What SequenceDataset hands the loop (datasets/sequence.py: Batch(trajectories, conditions)), as plain tuples."""
 
