@@ -83,7 +83,7 @@ def build_models(device):
     return diff, guide, cguide, (sd_u, sd_r, sd_c)
 
 
-def other_configs(device, steps=3, world=1, rank=0, rehearse=False):
+def other_configs(device, steps=3, world=1, rank=0, rehearse=False, only=None, bf16=True):
     """BASELINE configs 3 and 4, whole planning calls through the same ShardedPlanner path, synthetic seeded weights.
     One GPU: at their PER-GPU size (512 and 8192 candidates).  world > 1: at their GLOBAL size (4096 and 65536 candidates)
     sharded over the ranks -- strong scaling, with the score all-gather in the loop.  Reported next to the headline, not as `value`."""
@@ -92,11 +92,13 @@ def other_configs(device, steps=3, world=1, rank=0, rehearse=False):
     from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
     from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
     out = []
-    for name, obs, act, um, vm, Bgpu, Bglobal, kw in (
+    for idx, (name, obs, act, um, vm, Bgpu, Bglobal, kw) in enumerate((
             ('configs[2]: hopper-medium-v2 shapes, 4096 candidates / 8 GPUs', 11, 3, (1, 2, 4, 8), (1, 2, 4, 8), 512, 4096,
              dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0)),
             ('configs[3]: walker2d shapes, UNet dim_mults (1,4,8), 65536 candidates / 8 GPUs', 17, 6, (1, 4, 8),
-             (1, 2, 4, 8), 8192, 65536, dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0))):
+             (1, 2, 4, 8), 8192, 65536, dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0)))):
+        if only is not None and idx != only:
+            continue
         D = obs + act
         n_global = Bgpu if world == 1 else (min(Bglobal, 8192) if rehearse else Bglobal)
         lo, hi = shard_bounds(n_global, world, rank)
@@ -146,6 +148,9 @@ def other_configs(device, steps=3, world=1, rank=0, rehearse=False):
                  'algorithmic_gflop_per_trajectory': g_nom, 'executed_gflop_per_trajectory': g_exe,
                  'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS * world, 'unit': 'TFLOP/s (executed FLOPs)',
                  'frac': tf / (PEAK_F32_MFMA_TFLOPS * world)}
+        if not bf16:                       # profiling runs of one config (tools/bench_other.py): the fp32 path only
+            out.append(entry)
+            continue
         # the same call with the opt-in bf16x3 operands (engaged from 512 candidates per launch up), reported apart
         for net in (unet, guide._net(), cguide._net()):
             net.set_precision('bf16x3')
@@ -500,7 +505,9 @@ def main():
         traffic = None
         try:
             import glob
-            with open(sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')))[-1]) as f:   # newest round
+            files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_headline_hbm_traffic.json'))) or \
+                sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')))
+            with open(files[-1]) as f:                                             # newest round's headline-only run
                 traffic = json.load(f)['conv_gemm_kernel']['hbm_bytes_per_launch']
         except Exception:
             pass

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void time_block_bwd_kernel(const TBJob* jobs, 
   }
 }
 hipError_t launch_time_block_bwd(const TBJob* dev_jobs, int njobs, const float* temb, int dim, int T, hipStream_t st) {
-  hipLaunchKernelGGL(time_block_bwd_kernel, dim3(njobs, 8), dim3(256), 0, st, dev_jobs, temb, dim, T);
+  hipLaunchKernelGGL(time_block_bwd_kernel, dim3(njobs, 32), dim3(256), 0, st, dev_jobs, temb, dim, T);
   return hipGetLastError();
 }
 
