@@ -114,6 +114,27 @@ int trebi_unet_forward(trebi_net* net, const float* x, int ldx, const int64_t* t
  * temporal.py:18-46) is the channels-last tensor [B, L, ld] (first C columns) at workspace + offset_floats. */
 int trebi_unet_tap(const trebi_net* net, const char* block, int B, size_t* offset_floats, int* L, int* C, int* ld);
 
+/* Per-layer parity taps (no counterpart in the reference; its tests would put forward / backward hooks on the modules of
+ * helpers.py:30-63 and temporal.py:18-46).  A pass is the list of launches trebi_unet_forward / trebi_value_gradients make:
+ * pass 0 the forward -- one entry per Conv1dBlock (Conv1d + GroupNorm + Mish, with the block's time bias or residual folded
+ * in), Downsample1d, Upsample1d, final 1x1 conv, value head --, pass 1 the ValueFunction's backward-to-input (input-gradient
+ * convolutions with the GroupNorm + Mish backward as their prologue).  For a batch of B, entry `index` reads and writes the
+ * channels-last tensors described by its trebi_tensor_ref's: where = 0 absent, 1 workspace + offset_floats, 2 the call's x,
+ * 3 the call's output, 4 the call's gradient output; [B, L, ld] with the first C columns used (ld = 0: the caller's). */
+typedef struct { int where, L, C, ld; size_t offset_floats; } trebi_tensor_ref;
+typedef struct {
+  char name[120];          /* state_dict prefix of the layer's weight, " (dgrad)" appended for an input-gradient conv */
+  int kind;                /* 0 convolution stage, 1 value head */
+  int Lin, Lout, Cin, Cin2, N, stride, pad;
+  int phase_split;         /* ConvTranspose1d as two output phases: columns per phase, else 0 */
+  int group_norm, time_bias, prologue;
+  trebi_tensor_ref src, src2 /* 1x1 residual conv's input */, res /* identity residual */, dst;
+  trebi_tensor_ref saved_xhat, saved_gain /* mish'(z) * gamma */, saved_stats /* (mean, rstd) per group */;
+  trebi_tensor_ref pro_xhat, pro_gain, pro_stats;   /* what the backward prologue reads (a forward layer's saved_*) */
+} trebi_layer_info;
+int trebi_net_layer_count(const trebi_net* net, int pass);
+int trebi_net_layer_info(const trebi_net* net, int pass, int index, int B, trebi_layer_info* out);
+
 /* trebi_unet_forward with NO workspace argument and no allocation of any kind: the
  * activations go to a static per-GPU device array of TREBI_STATIC_SCRATCH_BYTES that the
  * library's code object carries (every GPU the library runs on holds it until the process

@@ -1906,6 +1906,46 @@ extern "C" int trebi_unet_tap(const trebi_net* net, const char* block, int B, si
   return fail(TREBI_BAD_ARG, "no ResidualTemporalBlock named '%s'", block);
 }
 
+// Per-layer parity taps: what every launch of a pass reads and writes, so that a test can hold ONE layer to the oracle's
+// Conv1dBlock / Downsample1d / Upsample1d / input-gradient unit on the very tensors the library fed it.
+extern "C" int trebi_net_layer_count(const trebi_net* net, int pass) {
+  if (!net || pass < 0 || pass > 1) return 0;
+  return (int)(pass ? net->bwd.size() : net->fwd.size());
+}
+
+extern "C" int trebi_net_layer_info(const trebi_net* net, int pass, int index, int B, trebi_layer_info* out) {
+  if (!net || !out || B < 1) return fail(TREBI_BAD_ARG, "null argument");
+  if (pass < 0 || pass > 1) return fail(TREBI_BAD_ARG, "pass must be 0 (forward) or 1 (backward-to-input)");
+  const std::vector<Op>& ops = pass ? net->bwd : net->fwd;
+  if (index < 0 || index >= (int)ops.size()) return fail(TREBI_BAD_ARG, "layer index %d outside 0..%zu", index, ops.size());
+  const Op& op = ops[index];
+  const std::vector<size_t> off = net->offsets(B);
+  memset(out, 0, sizeof *out);
+  snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
+  out->kind = op.kind; out->Lin = op.Lin; out->Lout = op.Lout; out->Cin = op.Cin; out->Cin2 = op.Cin2; out->N = op.N;
+  out->stride = op.stride; out->pad = op.pad; out->phase_split = op.osplit;
+  out->group_norm = op.gn ? 1 : 0; out->time_bias = op.tbias ? 1 : 0; out->prologue = op.pro ? 1 : 0;
+  auto ref = [&](const BufRef& r, int L, int C, trebi_tensor_ref* o) {
+    o->L = L; o->C = C;
+    if (r.id == NONE) return;
+    if (r.id >= 0) { o->where = 1; o->offset_floats = off[r.id] + r.coloff; o->ld = r.ld; }
+    else o->where = r.id == EXT_X ? 2 : r.id == EXT_OUT ? 3 : 4;
+  };
+  auto whole = [&](int id, int L, int C, trebi_tensor_ref* o) { ref(id == NONE ? BufRef{} : BufRef{id, C, 0}, L, C, o); };
+  ref(op.src, op.Lin, op.Cin, &out->src);
+  ref(op.src2, op.Lout, op.Cin2, &out->src2);
+  ref(op.res, op.Lout, op.N, &out->res);
+  if (op.osplit) ref(op.dst, 2 * op.Lout, op.osplit, &out->dst);
+  else ref(op.dst, op.Lout, op.N, &out->dst);
+  whole(op.save_y, op.Lout, op.N, &out->saved_xhat);
+  whole(op.save_g, op.Lout, op.N, &out->saved_gain);
+  whole(op.save_st, GN_GROUPS, 2, &out->saved_stats);
+  whole(op.pro_y, op.Lin, op.Cin, &out->pro_xhat);
+  whole(op.pro_g, op.Lin, op.Cin, &out->pro_gain);
+  whole(op.pro_st, GN_GROUPS, 2, &out->pro_stats);
+  return 0;
+}
+
 extern "C" int trebi_unet_forward(trebi_net* net, const float* x, int ldx, const int64_t* t, float* out, int ldo,
                                   int B, void* ws, size_t ws_bytes, void* stream) {
   if (!net || !x || !t || !out || !ws) return fail(TREBI_BAD_ARG, "null argument");

@@ -37,6 +37,19 @@ class TrainDesc(C.Structure):
                 ('loss_l1', C.c_int), ('n_cond', C.c_int), ('cond_index', C.c_int * 4)]
 
 
+class TensorRef(C.Structure):
+    _fields_ = [('where', C.c_int), ('L', C.c_int), ('C', C.c_int), ('ld', C.c_int), ('offset_floats', C.c_size_t)]
+
+
+class LayerInfo(C.Structure):
+    _fields_ = [('name', C.c_char * 120), ('kind', C.c_int), ('Lin', C.c_int), ('Lout', C.c_int), ('Cin', C.c_int),
+                ('Cin2', C.c_int), ('N', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('phase_split', C.c_int),
+                ('group_norm', C.c_int), ('time_bias', C.c_int), ('prologue', C.c_int),
+                ('src', TensorRef), ('src2', TensorRef), ('res', TensorRef), ('dst', TensorRef),
+                ('saved_xhat', TensorRef), ('saved_gain', TensorRef), ('saved_stats', TensorRef),
+                ('pro_xhat', TensorRef), ('pro_gain', TensorRef), ('pro_stats', TensorRef)]
+
+
 # name -> (restype, argtypes); every symbol the header declares
 _VP = C.c_void_p
 SIGNATURES = {
@@ -56,6 +69,8 @@ SIGNATURES = {
     'trebi_unet_forward': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     'trebi_unet_tap': (C.c_int, [_VP, C.c_char_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
+    'trebi_net_layer_count': (C.c_int, [_VP, C.c_int]),
+    'trebi_net_layer_info': (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.POINTER(LayerInfo)]),
     'trebi_unet_forward_static': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int, C.c_int, _VP]),
     'trebi_value_workspace_bytes': (C.c_size_t, [_VP, C.c_int]),
     'trebi_value_gradients': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t,

@@ -153,12 +153,38 @@ class _HipNet(nn.Module):
             raise RuntimeError(f'expected x of shape [batch, {self.horizon}, {self.transition_dim}], got {tuple(x.shape)}')
         return x.shape
 
+    _WS_KEEP = 4                                  # workspaces kept per net (most recently used batch sizes)
+
     def _workspace(self, B, device, query):
         key = (B, str(device))
-        if key not in self._ws:
+        ws = self._ws.pop(key, None)
+        if ws is None:
             nbytes = query(self.net_handle(device), B)
-            self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self._ws[key]
+            while len(self._ws) >= self._WS_KEEP:     # a sweep over batch sizes must not pin one buffer per size
+                self._ws.pop(next(iter(self._ws)))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._ws[key] = ws                            # (re-)inserted last: dicts keep insertion order
+        return ws
+
+    def layers(self, B, backward=False):
+        """Per-layer parity taps (trebi_net_layer_info): for every launch of the forward (or of the ValueFunction's
+        backward-to-input) on a batch of B, its descriptor and a function view(ref) -> the [B, L, C] tensor it names in the
+        workspace of the LAST call at that batch size (None for tensors that are the call's own arguments)."""
+        dev = next(self.parameters()).device
+        h = self.net_handle(dev)
+        ws = self._ws[(B, str(dev))].view(torch.float32)
+
+        def view(ref):
+            if ref.where != 1:
+                return None
+            o = ref.offset_floats
+            return ws[o:o + (B * ref.L - 1) * ref.ld + ref.C].as_strided((B, ref.L, ref.C), (ref.L * ref.ld, ref.ld, 1))
+        out = []
+        for i in range(_lib.lib().trebi_net_layer_count(h, 1 if backward else 0)):
+            info = _lib.LayerInfo()
+            _lib.check(_lib.lib().trebi_net_layer_info(h, 1 if backward else 0, i, B, C.byref(info)))
+            out.append(info)
+        return out, view
 
     def flops(self, backward=False):
         dev = next(self.parameters()).device
