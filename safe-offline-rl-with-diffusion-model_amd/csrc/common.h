@@ -123,6 +123,9 @@ struct Tile {
 size_t conv_lds_bytes(const ConvP& p, const Tile& tl);
 hipError_t conv_init_device();
 hipError_t launch_conv(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st);
+// narrow.hip: the 32 / 64-channel Conv1dBlocks at large batches (persistent workgroups, register-resident weights)
+bool narrow_ok(const ConvLaunch& L, int nz);
+hipError_t launch_narrow(const ConvLaunch& L, int nz, hipStream_t st);
 ConvGeo conv_make_geo(const ConvP& p, const Tile& tl);
 bool conv_w5_ok(const ConvP& p, const Tile& tl);     // the layer / tile pairs that take the channel-block-major K loop
 bool conv_vec_ok(const ConvP& p);

@@ -1067,6 +1067,7 @@ hipError_t conv_init_device() {
 }
 
 hipError_t launch_conv(const ConvLaunch& L, int nz, const Tile& tl, hipStream_t st) {
+  if (!tl.bf && narrow_ok(L, nz)) return launch_narrow(L, nz, st);
 #define TREBI_CASE(mi, ni, posmajor) \
   if (tl.MI == mi && tl.NI == ni && (tl.pm != 0) == posmajor) return launch_conv_t<mi, ni, posmajor>(L, nz, tl, st);
   TREBI_TILES(TREBI_CASE)

@@ -211,7 +211,9 @@ WgCfg wg_config(const TOp& t, int B) {
   // candidate stride = 16 (mod 64) floats: the four candidates of one MFMA operand read land in disjoint bank groups
   auto pad16 = [](int v) { return v + (((16 - v % 64) % 64) + 64) % 64; };
   c.SA = pad16(t.LA * c.ldAs); c.SB = pad16(t.LB * c.ldBs);
-  int S = (72 * 1024 / 4) / (c.SA + c.SB) / 4 * 4;
+  static const int lds_kb = getenv("TREBI_WG_LDS_KB") ? atoi(getenv("TREBI_WG_LDS_KB")) : 72;        // diagnostics
+  static const int wg_target = getenv("TREBI_WG_TARGET") ? atoi(getenv("TREBI_WG_TARGET")) : 512;
+  int S = (lds_kb * 1024 / 4) / (c.SA + c.SB) / 4 * 4;
   S = std::max(4, std::min(64, S));
   // the kernel prefetches the next chunk into registers where that takes at most 8 float4 per thread and operand
   const int Spf = std::min(std::min(S, 128 / t.LA / 4 * 4), 128 * c.nwa / (t.LB * c.NB) / 4 * 4);
@@ -221,7 +223,7 @@ WgCfg wg_config(const TOp& t, int B) {
     unsupported("weight gradient of a layer of length %d (%d x %d channels) is not tiled", std::max(t.LA, t.LB), t.CA, t.CB);
   c.S = S;
   const int ntiles = (c.CA16 / (16 * c.nwa)) * (c.CB16 / (16 * c.NB));
-  int ks = std::max(1, std::min((512 + ntiles - 1) / ntiles, (B + S - 1) / S));      // ~two workgroups per CU
+  int ks = std::max(1, std::min((wg_target + ntiles - 1) / ntiles, (B + S - 1) / S));      // ~two workgroups per CU
   c.spw = rup((B + ks - 1) / ks, S);
   c.ksplit = (B + c.spw - 1) / c.spw;
   c.slab_stride = (long)t.k * c.CB16 * c.CA16;

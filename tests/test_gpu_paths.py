@@ -21,6 +21,8 @@ CONFIGS = {
     'direct_single_layers': {'TREBI_DIRECT_SINGLE': '1', 'TREBI_CHAIN': '0'},
     # debug aid of SURVEY.md section 5: workspaces NaN-filled before every pass -- nothing may read what it did not write
     'value_head_as_its_own_kernel': {'TREBI_CHAIN_HEAD': '0'},
+    # narrow.hip: the persistent 32 / 64-channel kernel takes its layers from 2048 candidates up; here at every batch size
+    'persistent_narrow_layers_at_every_batch': {'TREBI_NARROW_MINB': '1', 'TREBI_CHAIN': '0'},
     'poisoned_workspaces': {'TREBI_POISON': '1'},
     'poisoned_workspaces_no_chains': {'TREBI_POISON': '1', 'TREBI_CHAIN': '0'},
 }
@@ -46,3 +48,26 @@ def test_full_size_copies_with_the_tap_major_loop():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+def _child(files, env, k=None, timeout=600):
+    cmd = [sys.executable, '-m', 'pytest'] + [os.path.join(HERE, f) for f in files] + \
+          ['-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', '--timeout', '200', '--timeout-method', 'thread']
+    if k:
+        cmd += ['-k', k]
+    r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+def test_units_nets_and_training_with_the_persistent_narrow_kernel():
+    """narrow.hip at small batches: every 32 / 64-channel Conv1dBlock and input-gradient layer (forward with saved operands, backward
+    behind the GroupNorm + Mish prologue, the training step's plain input gradients) against its oracle unit (test_gpu_ops.py), the
+    golden nets and guide gradients (test_gpu_nets.py) and the training goldens (test_gpu_train.py)."""
+    _child(['test_gpu_ops.py', 'test_gpu_nets.py', 'test_gpu_train.py'], {'TREBI_NARROW_MINB': '1'})
+
+
+def test_full_size_copies_without_the_persistent_narrow_kernel():
+    """test_gpu_fullsize.py runs the narrow layers of 8192 / 4100 candidates through narrow.hip (default from 2048 candidates up);
+    with it switched off the tiles it replaced stay pinned to the golden chains too."""
+    _child(['test_gpu_fullsize.py'], {'TREBI_NARROW': '0'}, k='walker148 or 4100')
