@@ -21,7 +21,7 @@ CONFIGS = {
     'direct_single_layers': {'TREBI_DIRECT_SINGLE': '1', 'TREBI_CHAIN': '0'},
     # debug aid of SURVEY.md section 5: workspaces NaN-filled before every pass -- nothing may read what it did not write
     'value_head_as_its_own_kernel': {'TREBI_CHAIN_HEAD': '0'},
-    # narrow.hip: the persistent 32 / 64-channel kernel takes its layers from 2048 candidates up; here at every batch size
+    # narrow.hip: the persistent 32 / 64-channel kernel takes its layers from 512 candidates up; here at every batch size
     'persistent_narrow_layers_at_every_batch': {'TREBI_NARROW_MINB': '1', 'TREBI_CHAIN': '0'},
     'poisoned_workspaces': {'TREBI_POISON': '1'},
     'poisoned_workspaces_no_chains': {'TREBI_POISON': '1', 'TREBI_CHAIN': '0'},
@@ -68,6 +68,6 @@ def test_units_nets_and_training_with_the_persistent_narrow_kernel():
 
 
 def test_full_size_copies_without_the_persistent_narrow_kernel():
-    """test_gpu_fullsize.py runs the narrow layers of 8192 / 4100 candidates through narrow.hip (default from 2048 candidates up);
+    """test_gpu_fullsize.py runs the narrow layers of 8192 / 4100 candidates through narrow.hip (default from 512 candidates up);
     with it switched off the tiles it replaced stay pinned to the golden chains too."""
-    _child(['test_gpu_fullsize.py'], {'TREBI_NARROW': '0'}, k='walker148 or 4100')
+    _child(['test_gpu_fullsize.py'], {'TREBI_NARROW': '0'}, k='walker148 or 4100 or hopper')
