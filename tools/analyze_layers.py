@@ -14,7 +14,7 @@ for d in dirs:
     f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        m = re.search(r'(conv_gemm_kernel|resident_chain_kernel|wgrad_kernel|gnb_kernel)(<[^>]*>)?', k)
+        m = re.search(r'(conv_gemm_kernel|narrow_conv_kernel|resident_chain_kernel|wgrad_kernel|gnb_kernel)(<[^>]*>)?', k)
         if not m:
             continue
         key = (m.group(1) + (m.group(2) or ''), int(r['Grid_Size']), int(r['Workgroup_Size']), int(r['LDS_Block_Size']))

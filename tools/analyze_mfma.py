@@ -22,7 +22,7 @@ disp = collections.defaultdict(set)
 dur = collections.defaultdict(float)
 for r in csv.DictReader(open(f)):
     k = r['Kernel_Name']
-    for key in ('conv_gemm_kernel', 'resident_chain_kernel', 'wgrad_kernel', 'gnb_kernel', 'wreduce_kernel'):
+    for key in ('conv_gemm_kernel', 'narrow_conv_kernel', 'resident_chain_kernel', 'wgrad_kernel', 'gnb_kernel', 'wreduce_kernel'):
         if key in k:
             k = key
             break

@@ -7,7 +7,7 @@ def load(d, name):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != name: continue
         k = r['Kernel_Name']
-        k = 'conv_gemm_kernel' if 'conv_gemm_kernel' in k else 'resident_chain_kernel' if 'resident_chain_kernel' in k else k[:40]
+        k = 'conv_gemm_kernel' if 'conv_gemm_kernel' in k else 'narrow_conv_kernel' if 'narrow_conv_kernel' in k else 'resident_chain_kernel' if 'resident_chain_kernel' in k else k[:40]
         out[k].append(float(r['Counter_Value']))
     return out
 fe, wr = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
