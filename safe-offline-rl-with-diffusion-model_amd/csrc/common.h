@@ -239,8 +239,9 @@ hipError_t launch_make_map(const float* coded, int* map, long n, hipStream_t st)
 hipError_t launch_qsample(const StepP& s, const float* x0, const float* noise, const long long* t, const float* sa,
                           const float* sb, float* out, int B, hipStream_t st);
 // weighted loss (helpers.py:159-167) + its gradient wrt the net output; loss_out[0] += weighted loss, [1] += a0 loss
-hipError_t launch_loss(const StepP& s, const float* pred, const float* targ, const float* w /*[H,D]*/, int l1,
-                       float inv_count, float inv_a0, float gscale, float* dout, float* loss_out, int B, hipStream_t st);
+constexpr int LOSS_BLOCKS = 512;
+hipError_t launch_loss(const StepP& s, const float* pred, const float* targ, const float* w, int l1, float inv_count,
+                       float inv_a0, float gscale, float* dout, float* partial, float* loss_out, int B, hipStream_t st);
 hipError_t launch_adam_ema(float* p, float* g, float* m, float* v, float* ema, long n, float b1, float b2, float step_size,
                            float inv_bc2_sqrt, float eps, int ema_mode, float ema_decay, hipStream_t st);
 hipError_t launch_time_embed_train(const float* w1, const float* b1, const float* w2, const float* b2, int dim, int T,

@@ -55,7 +55,7 @@ hipError_t launch_qsample(const StepP& s, const float* x0, const float* noise, c
 // =====================================================================================================
 __global__ __launch_bounds__(256) void loss_kernel(StepP s, const float* pred, const float* targ, const float* w, int l1,
                                                    float inv_count, float inv_a0, float gscale, float* dout,
-                                                   float* loss_out, int B) {
+                                                   float* partial, int B) {
   const size_t per = (size_t)s.H * s.D, total = (size_t)B * per;
   float ls = 0.f, as = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -75,17 +75,32 @@ __global__ __launch_bounds__(256) void loss_kernel(StepP s, const float* pred, c
   as = wave_sum(as);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ls; red[1][threadIdx.x >> 6] = as; }
   __syncthreads();
+  if (threadIdx.x == 0) {                      // per-workgroup partials, summed in a fixed order below (no float atomics)
+    partial[2 * blockIdx.x] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv_count;
+    partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv_a0;
+  }
+}
+__global__ __launch_bounds__(64) void loss_finish_kernel(const float* partial, int n, float* loss_out) {
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    a += partial[2 * i];
+    b += partial[2 * i + 1];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
   if (threadIdx.x == 0) {
-    atomicAdd(loss_out, (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv_count);
-    atomicAdd(loss_out + 1, (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv_a0);
+    loss_out[0] += a;
+    loss_out[1] += b;
   }
 }
 hipError_t launch_loss(const StepP& s, const float* pred, const float* targ, const float* w, int l1, float inv_count,
-                       float inv_a0, float gscale, float* dout, float* loss_out, int B, hipStream_t st) {
+                       float inv_a0, float gscale, float* dout, float* partial /* [2 * LOSS_BLOCKS] */, float* loss_out, int B,
+                       hipStream_t st) {
   const size_t total = (size_t)B * s.H * s.D;
-  int blocks = (int)std::min<size_t>((total + 255) / 256, 512);
+  int blocks = (int)std::min<size_t>((total + 255) / 256, LOSS_BLOCKS);
   hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(256), 0, st, s, pred, targ, w, l1, inv_count, inv_a0, gscale, dout,
-                     loss_out, B);
+                     partial, B);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, partial, blocks, loss_out);
   return hipGetLastError();
 }
 

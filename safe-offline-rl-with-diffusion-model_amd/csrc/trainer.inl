@@ -244,7 +244,7 @@ struct trebi_trainer {
   std::vector<int*> maps;           // per weight chunk of the net: packed position -> flat parameter index (or < 0)
   void* arena = nullptr;
   float *ws = nullptr, *xnoisy = nullptr, *pred = nullptr, *dout = nullptr, *wslab = nullptr;
-  float *lw = nullptr, *sa = nullptr, *sb = nullptr, *G = nullptr, *DT = nullptr;
+  float *lw = nullptr, *sa = nullptr, *sb = nullptr, *G = nullptr, *DT = nullptr, *lossp = nullptr;
   std::vector<float*> part;         // per backward step: its partial-sum table (kinds 1 and 3), or null
   std::vector<float*> part_time;    // per backward step: its per-timestep partial table (kind 1 with a time block)
   // reduction jobs, those of the tail bucket (final_conv, up path, mid blocks: tops[0..top_split)) first
@@ -370,7 +370,8 @@ extern "C" int trebi_trainer_create(trebi_ctx* ctx, const trebi_train_desc* desc
     if (t.kind == 1 && t.time_blk >= 0) blkC[t.time_blk] = t.C;
   for (int c : blkC) n_G += al((size_t)T * c);
   const size_t n_DT = al((size_t)nblk_t * T * dim), n_lw = al((size_t)H * D), n_tab = al(2 * (size_t)T);
-  const size_t total = n_ws + 3 * n_x + al(n_slab) + n_part + n_G + n_DT + n_lw + n_tab;
+  const size_t n_lossp = al(2 * LOSS_BLOCKS);
+  const size_t total = n_ws + 3 * n_x + al(n_slab) + n_part + n_G + n_DT + n_lw + n_tab + n_lossp;
   HIPCHK(hipMalloc(&tr->arena, total * sizeof(float)));
   float* p = (float*)tr->arena;
   tr->ws = p; p += n_ws;
@@ -393,6 +394,7 @@ extern "C" int trebi_trainer_create(trebi_ctx* ctx, const trebi_train_desc* desc
   tr->DT = p; p += n_DT;
   tr->lw = p; p += n_lw;
   tr->sa = p; tr->sb = p + T; p += n_tab;
+  tr->lossp = p; p += n_lossp;
   *out = tr.release();
   return 0;
 }
@@ -587,7 +589,7 @@ extern "C" int trebi_trainer_accumulate(trebi_trainer* tr, const float* x_start,
     if (int e = launch_op(net->fwd[i], r, tf[i], st)) return e;
   const float inv_count = 1.f / ((float)B * H * D), inv_a0 = d.action_dim > 0 ? 1.f / ((float)B * d.action_dim) : 0.f;
   HIPCHK(launch_loss(sp, tr->pred, d.predict_epsilon ? noise : x_start, tr->lw, d.loss_l1, inv_count, inv_a0,
-                     grad_scale * inv_count, tr->dout, loss_out, B, st));
+                     grad_scale * inv_count, tr->dout, tr->lossp, loss_out, B, st));
 
   // ---- backward ----
   // partial tables -> gradients and the per-block time Linears, per bucket: the tail bucket's parameters

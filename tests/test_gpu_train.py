@@ -283,13 +283,15 @@ def test_gradients_are_bit_reproducible():
     x, cond, t, noise = _batch(fx, 0, 0)
     idx = torch.arange(1500, device='cuda') % x.shape[0]
     tt = (t[idx] + torch.arange(1500, device='cuda')) % int(fx['T'])
-    outs = []
+    outs, losses = [], []
     for _ in range(3):
         eng.grads.zero_()
-        diff.p_losses(x[idx], {0: cond[0][idx]}, tt, noise=noise[idx])
+        loss, info = diff.p_losses(x[idx], {0: cond[0][idx]}, tt, noise=noise[idx])
         torch.cuda.synchronize()
         outs.append(eng.grads.clone())
+        losses.append((float(loss), float(info['a0_loss'])))
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert losses[0] == losses[1] == losses[2]           # the reported loss too: per-workgroup partials summed in a fixed order
     assert float(outs[0].abs().max()) > 0
 
 
