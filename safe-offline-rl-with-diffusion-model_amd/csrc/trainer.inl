@@ -223,7 +223,11 @@ WgCfg wg_config(const TOp& t, int B) {
     unsupported("weight gradient of a layer of length %d (%d x %d channels) is not tiled", std::max(t.LA, t.LB), t.CA, t.CB);
   c.S = S;
   const int ntiles = (c.CA16 / (16 * c.nwa)) * (c.CB16 / (16 * c.NB));
-  int ks = std::max(1, std::min((wg_target + ntiles - 1) / ntiles, (B + S - 1) / S));      // ~two workgroups per CU
+  // two-wave workgroups (the 32-channel layers: one tile set covers the whole weight matrix) get more of them: at 512 there
+  // is ONE wave per SIMD and nothing hides a wait
+  static const int wg_target2 = getenv("TREBI_WG_TARGET2") ? atoi(getenv("TREBI_WG_TARGET2")) : 1024;   // measured 13.23 (512) -> 13.11 (1024), 13.09 (2048), 13.11 (4096) ms per step
+  const int target = c.nwa <= 2 ? wg_target2 : wg_target;
+  int ks = std::max(1, std::min((target + ntiles - 1) / ntiles, (B + S - 1) / S));      // ~two workgroups per CU
   c.spw = rup((B + ks - 1) / ks, S);
   c.ksplit = (B + c.spw - 1) / c.spw;
   c.slab_stride = (long)t.k * c.CB16 * c.CA16;
