@@ -1665,6 +1665,8 @@ int build_plan(const std::vector<const std::vector<Op>*>& lists0, const std::vec
       snprintf(tb, sizeof tb, " MI%d NI%d NG%d KS%d S%d%s%s%s grid %dx%d", st.tl.MI, st.tl.NI, st.tl.NG, st.tl.KS, st.tl.S, st.tl.pm ? " pm" : "", st.tl.resg ? " resg" : "", st.tl.bf ? " bf16x3" : "",
                (B + st.tl.S - 1) / st.tl.S, op.Npad / (16 * st.tl.NI * st.tl.NG));
       st.name = op.name + (op.pro ? " (bwd)" : "") + tb;
+      if (!st.tl.bf && narrow_ok(st.L, nz))        // launch_conv routes it to narrow.hip: the tile above is not what runs
+        st.name = op.name + (op.pro ? " (bwd)" : "") + " narrow N" + std::to_string(op.Npad) + " L" + std::to_string(op.Lout) + " persistent";
     }
     plan.push_back(st);
     ++i;

@@ -12,7 +12,7 @@ from trebi_amd import spec, synth
 from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
 from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
 H, T, DIM = bench.H, bench.T, bench.DIM
-obs, act, um, vm, B = {1: (17, 6, (1, 2, 4, 8), (1, 2, 4, 8), 64), 2: (11, 3, (1, 2, 4, 8), (1, 2, 4, 8), 512),
+obs, act, um, vm, B = {4: (17, 6, (1, 2, 4, 8), (1, 2, 4, 8), 8192), 1: (17, 6, (1, 2, 4, 8), (1, 2, 4, 8), 64), 2: (11, 3, (1, 2, 4, 8), (1, 2, 4, 8), 512),
                        3: (17, 6, (1, 4, 8), (1, 2, 4, 8), 8192)}[which]
 if len(sys.argv) > 4:
     B = int(sys.argv[4])
@@ -32,8 +32,14 @@ if prec != 'f32':
         n.set_precision(prec)
 o = torch.randn(obs, device=dev)
 kw = dict(scale=0.1, t_stopgrad=2, n_guide_steps=2, cost_grad_weight=5.0, guide_type=0, guide=guide, cost_guide=cguide)
+if os.environ.get('LP_UNET_ONLY') == '1':          # the denoiser alone: the unguided loop (diffusion.py:19-29)
+    from trebi_amd.diffusion import default_sample_fn as fn
+    kw = {}
 for profile in (False, True):
-    diff.sample_raw((B, H, D), {0: o[None].expand(B, -1)}, sample_fn=fn, cost_threshold=1e9, profile=profile, **kw)
+    if kw:
+        diff.sample_raw((B, H, D), {0: o[None].expand(B, -1)}, sample_fn=fn, cost_threshold=1e9, profile=profile, **kw)
+    else:
+        diff.sample_raw((B, H, D), {0: o[None].expand(B, -1)}, sample_fn=fn, profile=profile)
     torch.cuda.synchronize()
 p = diff.last_profile
 print({k: (round(v, 1) if isinstance(v, float) else v) for k, v in p.items()})

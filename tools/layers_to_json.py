@@ -4,7 +4,7 @@ import json, re, sys
 rows = []
 for l in open(sys.argv[1]).read().splitlines()[1:]:
     n, tot, avg, tf, name = l.split('\t')
-    m = re.match(r'(.*?) ((?:MI\d.*)|(?:S\d+ .*))$', name) if 'chain[' not in name else None
+    m = re.match(r'(.*?) ((?:MI\d.*)|(?:S\d+ .*)|(?:narrow N\d+.*))$', name) if 'chain[' not in name else None
     layer, tile = (m.group(1), m.group(2)) if m else (name, '')
     rows.append({'layer': layer, 'tile': tile, 'launches': int(n), 'total_us': float(tot), 'avg_us': float(avg),
                  'gflop_per_launch': float(tf) * float(avg) * 1e-3, 'tflops': float(tf)})
