@@ -103,9 +103,12 @@ ConvGeo conv_make_geo(const ConvP& p, const Tile& tl) {
   static const bool late_on = !(getenv("TREBI_X2LATE") && atoi(getenv("TREBI_X2LATE")) == 0);
   // (only where the W5 kernel WILL be launched: it exists for vector-addressable sources only -- launch_conv_t -- so the
   // carve may not assume it for a source like the caller's x with a row stride of 23 floats)
-  g.x2late = (late_on && p.x2 && n2 <= nA && conv_w5_ok(p, tl) && conv_vec_ok(p)) ? 1 : 0;
+  // (a second source LARGER than the slab -- the up path's 1x1 residual conv reads the 2C-channel concat -- takes the slab's
+  // place all the same: the shared space is the larger of the two)
+  static const bool late_big = !(getenv("TREBI_X2LATE_BIG") && atoi(getenv("TREBI_X2LATE_BIG")) == 0);
+  g.x2late = (late_on && p.x2 && (n2 <= nA || late_big) && conv_w5_ok(p, tl) && conv_vec_ok(p)) ? 1 : 0;
   g.oSlab2 = g.x2late ? 0 : nA;
-  if (g.x2late) n2 = 0;
+  if (g.x2late) { nA = nA > n2 ? nA : n2; n2 = 0; }
   g.oY = nA + n2;
   g.red1 = g.KS * g.TM * g.TNp;
   int red = g.red1 * (p.x2 ? 2 : 1), stage = nA + n2 + nY;
