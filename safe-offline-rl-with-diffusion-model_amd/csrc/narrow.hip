@@ -355,6 +355,8 @@ int narrow_variant(const ConvP& p) {
       if (c1 == 64 && c2 == 32) return 6;
     } else if (p.N == 32 && p.Lout == 16) {                // the TemporalUnet's last up level
       if (c1 == 32 && c2 == 0) return 8;
+      if (c1 == 32 && c2 == 128) return 9;                 // its first block's second conv: the 1x1 residual reads the concat
+      if (c1 == 32 && c2 == 256) return 10;                // (dim_mults (1,4,8))
     }
     return 0;
   }
@@ -419,6 +421,8 @@ hipError_t launch_narrow(const ConvLaunch& L, int nz, hipStream_t st) {
     case 6: return launch_t<4, 1, 20, 2, true, false>(L, nz, st);
     case 7: return launch_t<2, 2, 10, 2, true, false>(L, nz, st);
     case 8: return launch_t<2, 1, 10, 0, true, false>(L, nz, st);
+    case 9: return launch_t<2, 1, 10, 8, true, false>(L, nz, st);
+    case 10: return launch_t<2, 1, 10, 16, true, false>(L, nz, st);
     case 11: return launch_t<2, 2, 10, 0, false, true>(L, nz, st);
     case 12: return launch_t<2, 2, 10, 2, false, true>(L, nz, st);
     case 13: return launch_t<4, 1, 20, 0, false, true>(L, nz, st);
