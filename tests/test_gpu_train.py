@@ -297,8 +297,8 @@ def test_gradients_are_bit_reproducible():
 
 def test_tail_bucket_is_final_at_its_event():
     """trebi_trainer_set_bucket_event: what a side stream reads of grads[bucket_split:] after waiting for the event equals
-    the finished gradient bit for bit (1500 samples: the down path's backward is still running then), and setting the
-    event changes no gradient."""
+    the finished gradient bit for bit, the event fires well before the call's last kernel (1500 samples: the down path's
+    backward takes ~1 ms), and setting the event changes no gradient."""
     fx = np.load(os.path.join(GOLDEN, 'train_halfcheetah.npz'))
     diff, _ = _model(fx)
     eng = diff.train_engine(max_batch=1500)
@@ -315,22 +315,23 @@ def test_tail_bucket_is_final_at_its_event():
     diff.p_losses(x[idx], {0: cond[0][idx]}, tt, noise=noise[idx])
     torch.cuda.synchronize()
     ref = eng.grads.clone()
-    ev = torch.cuda.Event()
+    ev, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev.record()
     side = torch.cuda.Stream()
     eng.grads.zero_()
     torch.cuda.synchronize()
     eng.set_bucket_event(ev)
     diff.p_losses(x[idx], {0: cond[0][idx]}, tt, noise=noise[idx])
+    end.record()
     eng.set_bucket_event(None)
     side.wait_event(ev)
     with torch.cuda.stream(side):
         early = eng.grads[split:].clone()
-        head_then = eng.grads[:split].clone()
     torch.cuda.synchronize()
     assert torch.equal(eng.grads, ref)
     assert torch.equal(early, ref[split:])
-    assert not torch.equal(head_then, ref[:split])      # the down path had not finished: the event is not just the end
+    # the event is not just the end of the call: the down path's backward (about a third of the backward's work) runs behind it
+    assert ev.elapsed_time(end) > 0.1, ev.elapsed_time(end)
 
 
 def test_two_bucket_all_reduce_on_the_device(tmp_path):
