@@ -28,7 +28,10 @@ def _mk(cls, sd, *a, **k):
                                         ('pendulum', 4100),
                                         # default chain policy: two candidates per workgroup (161-448) and four (449-512),
                                         # with a last workgroup that is not full
-                                        ('halfcheetah', 201), ('hopper', 447), ('halfcheetah', 450), ('pendulum', 511)])
+                                        ('halfcheetah', 201), ('hopper', 447), ('halfcheetah', 450), ('pendulum', 511),
+                                        # configs[3] over TWO GPUs (the scaling run's N = 2 leg): 32768 candidates per rank,
+                                        # ~75 GB of workspaces -- offsets past 2^31 bytes
+                                        ('walker148', 32768)])
 def test_copies_of_golden_candidates(name, total):
     from diffuser.models import TemporalUnet, ValueFunction, GaussianDiffusion, ValueDiffusion
     from diffuser.sampling import ValueGuide, n_step_guided_and_constrained_p_sample as fn
